@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/ref_*.npz from the compiled, unmodified reference.
+
+Runs only where /root/reference exists (the build container).  It builds oracle/_ref/ref_driver_*
+(oracle/Makefile target `ref`: g++ on oracle/ref_driver.cpp with -I/root/reference/src), runs it,
+and packs its raw dumps into small .npz fixtures.  The fixtures are DATA (inputs and the reference's
+outputs); no reference source is copied.  Commit the .npz files together with this script.
+
+    python tests/golden/make_golden.py            # regenerates every fixture (about a minute)
+"""
+import hashlib
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+ORACLE = os.path.join(ROOT, "oracle")
+
+
+def rd(d, name, dt):
+    return np.fromfile(os.path.join(d, name), dtype=dt)
+
+
+def run(tag, w, h, photons, passes, traced, r2, k, seed_eye, seed_photon, full):
+    exe = os.path.join(ORACLE, "_ref", f"ref_driver_{w}x{h}")
+    with tempfile.TemporaryDirectory() as d:
+        subprocess.check_call([exe, d, str(photons), str(passes), str(traced), repr(float(r2)), str(k),
+                               str(seed_eye), str(seed_photon)])
+        P = w * h
+        out = dict(meta=np.array([w, h, photons, passes, traced, k, seed_eye, seed_photon], np.int64),
+                   gather_r2=np.array([r2], np.float64))
+        if full:
+            out["xorshift_u32"] = rd(d, "xorshift_u32.bin", np.uint32).reshape(3, 16)
+            out["xorshift_01"] = rd(d, "xorshift_01.bin", np.float64).reshape(3, 16)
+            out["mt_samples_seed4242"] = rd(d, "mt_samples_seed4242.bin", np.float64)
+            out["encode_in"] = rd(d, "encode_in.bin", np.float64).reshape(-1, 3)
+            out["encode_rgbe"] = rd(d, "encode_rgbe.bin", np.uint8).reshape(-1, 4)
+            out["encode_toint"] = rd(d, "encode_toint.bin", np.int32).reshape(-1, 3)
+            out["cam_rays"] = rd(d, "cam_rays.bin", np.float64).reshape(P, 6)
+            out["cam_hit_id"] = rd(d, "cam_hit_id.bin", np.int32)
+            out["cam_hit_f"] = rd(d, "cam_hit_f.bin", np.float64).reshape(P, 7)
+            out["rnd_rays"] = rd(d, "rnd_rays.bin", np.float64).reshape(-1, 6)
+            out["rnd_hit_id"] = rd(d, "rnd_hit_id.bin", np.int32)
+            out["rnd_hit_f"] = rd(d, "rnd_hit_f.bin", np.float64).reshape(-1, 7)
+        stride = 1 if full else 16
+        for i in range(passes):
+            hp_i = rd(d, f"eye_hp_i_pass{i}.bin", np.int32).reshape(P, 2)
+            hp_f = rd(d, f"eye_hp_f_pass{i}.bin", np.float64).reshape(P, 13)
+            ld = rd(d, f"eye_ld_pass{i}.bin", np.float64).reshape(P, 3)
+            st_n = rd(d, f"state_n_pass{i}.bin", np.int32)
+            st_f = rd(d, f"state_f_pass{i}.bin", np.float64).reshape(P, 4)
+            img = rd(d, f"image_pass{i}.bin", np.float64).reshape(P, 3)
+            out[f"eye_words_pass{i}"] = rd(d, f"eye_words_pass{i}.bin", np.uint64)
+            out[f"hp_valid_pass{i}"] = hp_i[:, 0].astype(np.int8)
+            out[f"hp_obj_pass{i}"] = hp_i[:, 1].astype(np.int8)
+            out[f"state_n_pass{i}"] = st_n
+            # sums in a fixed order pin the arrays that are only stored strided
+            out[f"sums_pass{i}"] = np.array([hp_f.sum(), ld.sum(), st_f.sum(), img.sum()])
+            out[f"hp_f_pass{i}"] = hp_f[::stride]
+            out[f"ld_pass{i}"] = ld[::stride]
+            out[f"state_f_pass{i}"] = st_f[::stride]
+            out[f"image_pass{i}"] = img[::stride]
+            out[f"ph_words_pass{i}"] = rd(d, f"ph_words_pass{i}.bin", np.int32)
+            out[f"ph_acc_off_pass{i}"] = rd(d, f"ph_acc_off_pass{i}.bin", np.int32)
+            out[f"ph_acc_pix_pass{i}"] = rd(d, f"ph_acc_pix_pass{i}.bin", np.int32)
+            out[f"ph_acc_cnt_pass{i}"] = rd(d, f"ph_acc_cnt_pass{i}.bin", np.int32).astype(np.int8)
+        out["stride"] = np.array([stride])
+        hdr = open(os.path.join(d, "final.hdr"), "rb").read()
+        ppm = open(os.path.join(d, "final.ppm"), "rb").read()
+        out["final_hdr"] = np.frombuffer(hdr, np.uint8)
+        if full:
+            out["final_ppm"] = np.frombuffer(ppm, np.uint8)
+        else:
+            out["final_ppm_sha256"] = np.frombuffer(hashlib.sha256(ppm).digest(), np.uint8)
+        path = os.path.join(HERE, f"ref_{tag}.npz")
+        np.savez_compressed(path, **out)
+        print(f"wrote {path}: {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+def main():
+    if not os.path.isdir("/root/reference/src"):
+        sys.exit("the reference is not present here; fixtures can only be regenerated in the build container")
+    subprocess.check_call(["make", "-C", ORACLE, "ref"])
+    # tag, W, H, photons/pass, passes, per-photon-traced, search r^2, K cap, seeds, full dump
+    run("64x48", 64, 48, 20000, 3, 4096, 25.0, 100000, 1000, 2000, True)
+    run("64x48_r5", 64, 48, 20000, 2, 1024, 5.0, 10000, 31, 77, False)   # main.cpp:76-80's r=5, K=10000
+    run("320x240", 320, 240, 200000, 2, 1024, 25.0, 100000, 1000, 2000, False)
+
+
+if __name__ == "__main__":
+    main()
