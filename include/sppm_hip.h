@@ -1,0 +1,161 @@
+/* sppm_hip.h -- C ABI of libsppm_hip.so: the MI355X (gfx950) implementation of the reference's
+ * stochastic progressive photon mapping path.
+ *
+ * The reference (0V/raytracer) has no plugin or FFI interface; its boundary is source-level C++
+ * (SURVEY.md section 8b).  Each entry point below names the reference interface it replaces
+ * (file:line relative to the reference root).  include/sppm2_hip.hpp keeps the reference's C++
+ * names (edupt::Sphere, photonmap::sppm2::StochasticPpm<W,H>::render, save_hdr_file ...) on top of
+ * this ABI; INTEGRATION.md shows the binding a maintainer of the reference would add.
+ *
+ * Conventions: plain pointers and sizes only.  Pointers named d_* are DEVICE pointers (HBM, the
+ * current HIP device of the context), h_* are host pointers.  Every function returns 0 on success
+ * and a negative sppm_status otherwise; sppm_last_error() gives the text.  A context is bound to
+ * the HIP device that was current when it was created and to one HIP stream; calls on one context
+ * must not overlap.  Nothing here falls back to a CPU path: without a GPU sppm_create fails.
+ *
+ * Arithmetic is IEEE double throughout (the reference is double end to end, src/vec.h:9; FP32
+ * cannot reproduce first-hit ids on the radius-1e5 wall spheres), built with
+ * -ffp-contract=off, with cos/sin/pow5 from raytracer_amd/csrc/detmath.h, so results are
+ * bit-identical to oracle/sppm_oracle.c in its (sampler=XorShift, math=detmath) mode.
+ */
+#ifndef SPPM_HIP_H
+#define SPPM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum sppm_status {
+    SPPM_OK = 0,
+    SPPM_ERR_INVALID = -1,   /* bad argument */
+    SPPM_ERR_HIP = -2,       /* a HIP call failed (no device, out of memory, launch failure) */
+    SPPM_ERR_OVERFLOW = -3,  /* a device buffer was too small; nothing was dropped silently */
+    SPPM_ERR_STATE = -4      /* calls made in an order the path does not allow */
+} sppm_status;
+
+/* edupt::ReflectionType, src/material.h:10-15 */
+enum { SPPM_DIFFUSE = 0, SPPM_SPECULAR = 1, SPPM_REFRACTION = 2 };
+
+/* edupt::Sphere, src/sphere.h:15-27 (88 bytes, same field order) */
+typedef struct sppm_sphere {
+    double radius;
+    double position[3];
+    double emission[3];
+    double color[3];
+    int32_t reflection_type;
+    int32_t pad_;
+} sppm_sphere;
+
+/* Everything StochasticPpm<W,H> holds as members or takes in render():
+ * src/sppm2.h:38-64 (tunables, camera), :562-564 (render arguments). */
+typedef struct sppm_config {
+    int32_t width, height, samples, supersamples;
+    double camera_position[3], camera_dir[3], camera_up[3]; /* camera_dir already normalised, as src/sppm2.h:49 passes it */
+    double screen_height, screen_dist;                       /* src/sppm2.h:54-56 */
+    double alpha;            /* src/sppm2.h:39 */
+    double initial_radius2;  /* src/sppm2.h:44 */
+    double gather_radius2;   /* render()'s gather_photon_radius; a SQUARED bound (src/kdtree.h:57,126) */
+    int64_t gather_max;      /* render()'s gahter_max_photon_num; the kd search's K cap (src/kdtree.h:58).
+                                This build implements the uncapped set; sppm_photon_pass reports
+                                SPPM_ERR_OVERFLOW through sppm_check() if a query would exceed K
+                                (only when check_gather_max != 0). */
+    int32_t update_rule;     /* 0: per-photon shrink, src/sppm2.h:391-421 (default, the live SPPM)
+                                1: per-pass (N, tau) update, src/stochastic_ppm.h:721-741 */
+    int32_t double_nee;      /* 1 reproduces the reference's first-sight double direct sample
+                                (`break` leaves the switch, src/sppm2.h:204-227); 0 switches it off */
+    uint32_t seed_eye, seed_photon;
+    int64_t photons_per_pass; /* photons of one pass over ALL ranks; keys the per-photon XorShift
+                                 streams (key = pass*photons_per_pass + i), so a photon's path does
+                                 not depend on which GPU traces it */
+    int32_t pixel_first, pixel_count; /* this rank's slice of image indices for the gather/update
+                                         (0,0 = all).  Eye pass and tracing always cover what the
+                                         calls ask for; see sppm_gather. */
+    int32_t check_gather_max;
+    int32_t reserved_[3];
+} sppm_config;
+
+typedef struct sppm_ctx sppm_ctx;
+
+const char* sppm_last_error(void);
+int sppm_device_count(void);
+
+/* Replaces constructing StochasticPpm<W,H>(samples, supersamples) (src/sppm2.h:90-97) plus the
+ * allocations at the top of render() (src/sppm2.h:581,615-619).  `stream` is a hipStream_t (NULL =
+ * the default stream).  The scene is copied to the device (the reference compiles it in,
+ * src/scene.h:12-24). */
+int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres, int32_t n_spheres, void* stream, sppm_ctx** out);
+int sppm_destroy(sppm_ctx* ctx);
+
+/* edupt::PinholeCamera::get_ray for every pixel (src/cameras.h:52-64): d_rays[(y*W+x)*6 + 0..5] =
+ * origin xyz, direction xyz. */
+int sppm_camera_rays(sppm_ctx* ctx, int32_t supersample_x, int32_t supersample_y, double* d_rays);
+
+/* edupt::intersect_scene over a batch of rays (src/scene.h:53-76 calling src/sphere.h:31-56).
+ * d_rays[n][6]; d_id[n] = object id or -1; d_hit[n][7] = distance, position xyz, normal xyz
+ * (distance = 1e128 and zeros on a miss). */
+int sppm_intersect(sppm_ctx* ctx, const double* d_rays, int64_t n, int32_t* d_id, double* d_hit);
+
+/* One eye pass: the y/x/sy/sx/s loops of render() calling create_point_loop (src/sppm2.h:625-646,
+ * :156-315) including next_event_est (src/radiance.h:29-70).  One XorShift stream per
+ * (pass, image index).  Replaces CreateKDtree too (src/sppm2.h:649): nothing is built over the
+ * hitpoints, the photon records are gridded instead. */
+int sppm_eye_pass(sppm_ctx* ctx, int32_t pass);
+
+/* Photon pass = update_photons (src/sppm2.h:527-558): photons [first, first+count) of this pass are
+ * emitted and traced (create_photon, src/sppm2.h:317-525) and their diffuse hits are applied to
+ * this rank's hitpoints in photon order with the update rule of the config.  Equivalent to
+ * sppm_trace + sppm_gather in batches sized to the record buffer. */
+int sppm_photon_pass(sppm_ctx* ctx, int32_t pass, int64_t first, int64_t count);
+
+/* The two halves of a photon pass, for multi-GPU use (trace a shard, exchange records, gather):
+ * sppm_trace appends the photon-hit records of photons [first, first+count) to the context's
+ * record buffer; sppm_records gives the device arrays (SoA: d_key[n], d_f[9][cap]: position,
+ * geometric normal, flux) so they can be all-gathered; sppm_set_records installs an external
+ * record set; sppm_gather applies the installed records and clears them. */
+int sppm_trace(sppm_ctx* ctx, int32_t pass, int64_t first, int64_t count);
+int sppm_records(sppm_ctx* ctx, uint64_t** d_key, double** d_f, int64_t* n, int64_t* cap);
+int sppm_set_record_count(sppm_ctx* ctx, int64_t n);
+int sppm_gather(sppm_ctx* ctx);
+
+/* End-of-pass update of rule 1 (src/stochastic_ppm.h:721-741); a no-op for rule 0. */
+int sppm_end_pass(sppm_ctx* ctx);
+
+/* Image assembly, src/sppm2.h:658-670: d_image[P][3] = ld/(pass+1) + flux/(pi r^2 (pass+1) photon_num). */
+int sppm_resolve(sppm_ctx* ctx, int32_t pass, int64_t photon_num, double* d_image);
+
+/* get_hdr_pixel on the device (src/hdr.h:37-45): d_rgbe[n][4]. */
+int sppm_hdr_pixels(sppm_ctx* ctx, const double* d_rgb, int64_t n, uint8_t* d_rgbe);
+/* save_hdr_file / save_ppm_file (src/hdr.h:48-89, src/ppm.h:22-29) on a HOST image [h][w][3]. */
+int sppm_save_hdr_file(const char* filename, const double* h_image, int32_t width, int32_t height);
+int sppm_save_ppm_file(const char* filename, const double* h_image, int32_t width, int32_t height);
+
+/* Waits for the context's stream and reports a deferred device-side error (record overflow, K cap). */
+int sppm_check(sppm_ctx* ctx);
+
+/* Taps for parity tests.  Host output arrays, any may be NULL.
+ * Hitpoints by image index: valid[P], obj[P] (-1 if none), hp_f[P][10] = distance, position,
+ * normal, weight; r2[P]; n[P]; flux[P][3]; ld[P][3]. */
+int sppm_download_hitpoints(sppm_ctx* ctx, int32_t* h_valid, int32_t* h_obj, double* h_hp_f, double* h_r2,
+                            int32_t* h_n, double* h_flux, double* h_ld);
+/* Records currently in the buffer, sorted by key: key[n] (photon<<16 | depth<<1 | orient),
+ * f[n][9] = position, geometric normal, flux.  Returns the count through n (call with NULL arrays
+ * to size). */
+int sppm_download_records(sppm_ctx* ctx, uint64_t* h_key, double* h_f, int64_t* n);
+/* Accepted (record key, image index) pairs of the gathers since the tap was enabled, sorted by
+ * (key, index).  Enable with cap > 0 before the photon pass. */
+int sppm_accept_tap(sppm_ctx* ctx, int64_t cap);
+int sppm_download_accepted(sppm_ctx* ctx, uint64_t* h_key, int32_t* h_pix, int64_t* n);
+
+/* counters since creation: [0] rays cast, [1] photons traced, [2] photon-hit records, [3] candidate
+ * (record, hitpoint) pairs examined, [4] accepted hitpoint updates, [5] gather batches,
+ * [6] nanoseconds of device time in the gather kernel as measured by HIP events when timing is on,
+ * [7] gather kernel launches timed. */
+int sppm_counters(sppm_ctx* ctx, uint64_t h_out[8]);
+int sppm_set_timing(sppm_ctx* ctx, int32_t on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,192 @@
+// sppm_device.hpp -- device-side building blocks of the SPPM path (gfx950, FP64).
+//
+// Every function keeps the association order of the reference expression it implements (cited
+// per function, paths relative to the reference root) so that, built with -ffp-contract=off, the
+// results are bit-identical to oracle/sppm_oracle.c (sampler = XorShift, math = detmath).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/sppm_hip.h"
+#include "detmath.h"
+
+#define SPPM_PI 3.14159265358979323846
+#define SPPM_EPS 1e-6   // src/constant.h:8
+#define SPPM_INF 1e128  // src/constant.h:7
+#define SPPM_IOR 1.5    // src/material.h:17
+#define SPPM_KDEPTH 5   // src/radiance.h:17
+
+struct d3 { double x, y, z; };
+
+__device__ __forceinline__ d3 mk(double x, double y, double z) { d3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ d3 ld3(const double* p) { return mk(p[0], p[1], p[2]); }
+// src/vec.h:11-25
+__device__ __forceinline__ d3 operator+(d3 a, d3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ d3 operator-(d3 a, d3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ d3 operator*(d3 a, double b) { return mk(a.x * b, a.y * b, a.z * b); }
+__device__ __forceinline__ d3 operator/(d3 a, double b) { return mk(a.x / b, a.y / b, a.z / b); }
+__device__ __forceinline__ double dot(d3 a, d3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ double len2(d3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
+__device__ __forceinline__ d3 normalize(d3 a) { return a * (1.0 / sqrt(len2(a))); }
+__device__ __forceinline__ d3 had(d3 a, d3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ d3 cross(d3 a, d3 b)
+{
+    return mk((a.y * b.z) - (a.z * b.y), (a.z * b.x) - (a.x * b.z), (a.x * b.y) - (a.y * b.x));
+}
+__device__ __forceinline__ double max3(d3 c) { const double m = c.y > c.z ? c.y : c.z; return c.x > m ? c.x : m; }
+
+// ---- edupt::XorShift, src/random.h:9-33, plus this build's stream derivation -------------------
+struct XorShift {
+    uint32_t s0, s1, s2, s3;
+    __device__ __forceinline__ void seed(uint32_t initial_seed)
+    {
+        uint32_t s = initial_seed;
+        s0 = s = 1812433253u * (s ^ (s >> 30)) + 1u;
+        s1 = s = 1812433253u * (s ^ (s >> 30)) + 2u;
+        s2 = s = 1812433253u * (s ^ (s >> 30)) + 3u;
+        s3 = s = 1812433253u * (s ^ (s >> 30)) + 4u;
+    }
+    __device__ __forceinline__ uint32_t next()
+    {
+        const uint32_t t = s0 ^ (s0 << 11);
+        s0 = s1; s1 = s2; s2 = s3;
+        return s3 = (s3 ^ (s3 >> 19)) ^ (t ^ (t >> 8));
+    }
+    // (double)next() / UINT_MAX, src/random.h:23 (can return exactly 1.0, as the reference's can)
+    __device__ __forceinline__ double next01() { return (double)next() / 4294967295.0; }
+};
+__device__ __forceinline__ uint32_t fmix32(uint32_t h)
+{
+    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+    return h;
+}
+// Low 32 key bits through a bijective mixer (distinct keys < 2^32 -> distinct seeds), expanded by
+// the reference's constructor; high key bits perturb the second state word.
+__device__ __forceinline__ XorShift make_stream(uint32_t base, uint64_t key)
+{
+    XorShift r;
+    r.seed(fmix32((uint32_t)key ^ base));
+    r.s1 ^= (uint32_t)(key >> 32) * 0x9E3779B9u;
+    return r;
+}
+
+// ---- scene ----------------------------------------------------------------------------------
+struct Hit { double distance; d3 position, normal; int object_id; };
+
+// edupt::intersect_scene, src/scene.h:53-76, over Sphere::intersect, src/sphere.h:31-56.
+// The sphere index is wave-uniform, so the sphere fields come through scalar loads.
+__device__ __forceinline__ bool intersect_scene(const sppm_sphere* __restrict__ sp, int ns, d3 org, d3 dir, Hit& h)
+{
+    double best = SPPM_INF;
+    int id = -1;
+    for (int i = 0; i < ns; i++) {
+        const d3 p_o = ld3(sp[i].position) - org;
+        const double b = dot(p_o, dir);
+        const double D4 = b * b - dot(p_o, p_o) + sp[i].radius * sp[i].radius;
+        if (D4 < 0.0) continue;
+        const double sq = sqrt(D4);
+        const double t1 = b - sq, t2 = b + sq;
+        if (t1 < SPPM_EPS && t2 < SPPM_EPS) continue;
+        const double t = (t1 > SPPM_EPS) ? t1 : t2;
+        if (t < best) { best = t; id = i; }
+    }
+    h.distance = best;
+    h.object_id = id;
+    if (id < 0) return false;
+    h.position = org + dir * best;                            // sphere.h:53
+    h.normal = normalize(h.position - ld3(sp[id].position));  // sphere.h:54
+    return true;
+}
+
+// edupt::PinholeCamera, src/cameras.h:34-64
+struct Camera { d3 pos, sx, sy, center; double w, h, ss; };
+__device__ __host__ inline Camera make_camera_fields(const double* pos, const double* sx, const double* sy,
+                                                     const double* center, double w, double h, double ss)
+{
+    Camera c;
+    c.pos.x = pos[0]; c.pos.y = pos[1]; c.pos.z = pos[2];
+    c.sx.x = sx[0]; c.sx.y = sx[1]; c.sx.z = sx[2];
+    c.sy.x = sy[0]; c.sy.y = sy[1]; c.sy.z = sy[2];
+    c.center.x = center[0]; c.center.y = center[1]; c.center.z = center[2];
+    c.w = w; c.h = h; c.ss = ss;
+    return c;
+}
+__device__ __forceinline__ void camera_ray(const Camera& c, double x, double y, int sx, int sy, d3& org, d3& dir)
+{
+    const double rate = (1.0 / c.ss);
+    const double r1 = sx * rate + rate / 2.0;
+    const double r2 = sy * rate + rate / 2.0;
+    const d3 sp = c.center + c.sx * ((r1 + x) / c.w - 0.5) + c.sy * ((r2 + y) / c.h - 0.5);
+    org = c.pos;
+    dir = normalize(sp - c.pos);
+}
+
+__device__ __forceinline__ d3 reflect_dir(d3 d, d3 n) { return d - n * 2.0 * dot(n, d); }
+
+// the (u, v) of an orthonormal basis around w: src/sppm2.h:334-342, :435-443
+__device__ __forceinline__ void basis(d3 w, d3& u, d3& v)
+{
+    if (fabs(w.x) > 0.1) u = normalize(cross(mk(0.0, 1.0, 0.0), w));
+    else u = normalize(cross(mk(1.0, 0.0, 0.0), w));
+    v = cross(w, u);
+}
+// cosine_sampling, src/sppm2.h:138-144
+__device__ __forceinline__ d3 cosine_sampling(d3 w, d3 u, d3 v, XorShift& rng)
+{
+    const double u1 = 2 * SPPM_PI * rng.next01();
+    const double u2 = rng.next01();
+    const double u3 = sqrt(u2);
+    double sn, cs;
+    dm_sincos(u1, &sn, &cs);
+    return normalize((u * cs * u3 + v * sn * u3 + w * sqrt(1.0 - u2)));
+}
+
+// next_event_est, src/radiance.h:29-70
+__device__ __forceinline__ d3 next_event_est(const sppm_sphere* __restrict__ sp, int ns, const Hit& is, d3 on,
+                                             XorShift& rng, uint32_t& rays)
+{
+    if (is.object_id == 0) return mk(0, 0, 0);
+    const double r1 = 2 * SPPM_PI * rng.next01();
+    const double r2 = 1.0 - 2.0 * rng.next01();
+    const double r3 = sqrt(1.0 - r2 * r2);
+    double sn, cs;
+    dm_sincos(r1, &sn, &cs);
+    const d3 lc = ld3(sp[0].position);
+    const d3 lp = lc + normalize(mk(r3 * cs, r3 * sn, r2)) * (sp[0].radius + SPPM_EPS);
+    d3 ldir = lp - is.position;
+    const double dist2 = dot(ldir, ldir);
+    ldir = normalize(ldir);
+    const d3 ln = normalize(lp - lc);
+    const double dot0 = dot(on, ldir);
+    const double dot1 = dot(ln, ldir);
+    const double radius2 = sp[0].radius * sp[0].radius;
+    Hit sh;
+    rays++;
+    const bool hit = intersect_scene(sp, ns, is.position, ldir, sh);
+    if (hit && sh.object_id == 0 && dot1 < 0 && dot0 > 0) {
+        const double G = (fabs(dot0) * fabs(dot1)) / dist2;
+        const double pdf = 1.0 / (4.0 * SPPM_PI * radius2);
+        const d3 fs = ld3(sp[is.object_id].color) / SPPM_PI;
+        return had(ld3(sp[0].emission), fs) * G / pdf;
+    }
+    return mk(0, 0, 0);
+}
+
+// Shared glass interface logic of src/sppm2.h:245-293 (eye) and :465-520 (photon): returns false
+// on total internal reflection; otherwise the refracted direction and the Fresnel reflectance.
+// `eye` selects the eye path's cosine term (dot(t, -on)) against the photon's (dot(t, n)).
+__device__ __forceinline__ bool glass(d3 dir, d3 n, d3 on, bool eye, bool& into, double& nnt, d3& tdir, double& Re)
+{
+    into = dot(n, on) > 0.0;
+    const double nc = 1.0, nt = SPPM_IOR;
+    nnt = into ? nc / nt : nt / nc;
+    const double ddn = dot(dir, on);
+    const double cos2t = 1.0 - nnt * nnt * (1.0 - ddn * ddn);
+    if (cos2t < 0.0) return false;
+    tdir = normalize(dir * nnt - n * (into ? 1.0 : -1.0) * (ddn * nnt + sqrt(cos2t)));
+    const double a = nt - nc, b = nt + nc;
+    const double R0 = (a * a) / (b * b);
+    const double c = 1.0 - (into ? -ddn : (eye ? dot(tdir, on * -1.0) : dot(tdir, n)));
+    Re = R0 + (1.0 - R0) * dm_pow5(c);
+    return true;
+}

@@ -1,0 +1,1049 @@
+// sppm_kernels.hip -- gfx950 kernels and the C ABI (include/sppm_hip.h) of the SPPM path.
+//
+// Data layout in HBM (P = pixels = hitpoint slots, R = photon-hit records of one batch):
+//   hitpoints, SoA by component, indexed by image index:
+//     hp_pos[3][P] hp_nrm[3][P] hp_w[3][P] hp_flux[3][P] ld[3][P]  (f64)
+//     hp_r2[P] hp_dist[P] (f64)  hp_n[P] hp_obj[P] hp_valid[P] (i32)
+//     rule 1 only: hp_phi[3][P] hp_tau[3][P] hp_nd[P] (f64) hp_madd[P] (i32)
+//   photon-hit records, SoA: key[R] (u64: photon<<16 | depth<<1 | orient), f[9][Rcap] (position,
+//     geometric normal, flux).  Traced into the *unsorted* arrays by atomic append, then
+//     counting-sorted by hash-grid bucket into the *sorted* arrays each batch.
+//
+// Why records are gridded and hitpoints gather (instead of hitpoints gridded and photons
+// scattering with atomics): the reference's update (src/sppm2.h:391-421) is applied per photon,
+// in photon order, and each accepted photon shrinks the hitpoint's radius, which decides whether
+// later photons are accepted.  A hitpoint's final state is a sequential function of the
+// time-ordered photons near it -- but photon PATHS do not depend on hitpoints.  So photons are
+// traced in parallel, and each hitpoint replays "its" photons in key (= photon, bounce) order in
+// registers: exact reference semantics, no atomics on hitpoint data, deterministic.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "sppm_device.hpp"
+
+// ================================ kernels ==========================================================
+
+struct DevScene { const sppm_sphere* sp; int ns; };
+
+__global__ void k_camera_rays(Camera cam, int W, int H, int sx, int sy, double* __restrict__ rays)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= W * H) return;
+    const int x = i % W, y = i / W;
+    d3 o, d;
+    camera_ray(cam, x, y, sx, sy, o, d);
+    double* r = rays + 6 * (size_t)i;
+    r[0] = o.x; r[1] = o.y; r[2] = o.z; r[3] = d.x; r[4] = d.y; r[5] = d.z;
+}
+
+__global__ void k_intersect(DevScene sc, const double* __restrict__ rays, int64_t n, int32_t* __restrict__ id,
+                            double* __restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Hit h;
+    const bool hit = intersect_scene(sc.sp, sc.ns, ld3(rays + 6 * i), ld3(rays + 6 * i + 3), h);
+    id[i] = hit ? h.object_id : -1;
+    double* o = out + 7 * i;
+    o[0] = h.distance;
+    if (hit) { o[1] = h.position.x; o[2] = h.position.y; o[3] = h.position.z; o[4] = h.normal.x; o[5] = h.normal.y; o[6] = h.normal.z; }
+    else { o[1] = o[2] = o[3] = o[4] = o[5] = o[6] = 0.0; }
+}
+
+struct HpArrays {
+    double *pos, *nrm, *w, *flux, *ld, *phi, *tau;  // [3][P]
+    double *r2, *dist, *nd;
+    int32_t *n, *obj, *valid, *madd;
+    int P;
+};
+
+struct EyeParams {
+    Camera cam; int W, H, samples, supersamples; int pass; uint32_t seed_eye; double initial_r2; int double_nee;
+};
+
+// One thread per pixel: the loops of src/sppm2.h:625-646 around create_point_loop (:156-315).
+__global__ void __launch_bounds__(256) k_eye_pass(DevScene sc, EyeParams ep, HpArrays hp, unsigned long long* __restrict__ counters)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int P = ep.W * ep.H;
+    uint32_t rays = 0;
+    if (t < P) {
+        const int x = t % ep.W, y = t / ep.W;
+        const int index = (ep.H - y - 1) * ep.W + x;
+        XorShift rng = make_stream(ep.seed_eye, (uint64_t)ep.pass * (uint64_t)P + (uint64_t)index);
+        d3 ld = mk(hp.ld[index], hp.ld[P + index], hp.ld[2 * P + index]);
+        int valid = hp.valid[index];
+        for (int sy = 0; sy < ep.supersamples; sy++)
+            for (int sx = 0; sx < ep.supersamples; sx++)
+                for (int s = 0; s < ep.samples; s++) {
+                    d3 org, dir;
+                    camera_ray(ep.cam, x, y, sx, sy, org, dir);
+                    int depth = -1;
+                    bool direct = true;
+                    d3 weight = mk(1, 1, 1);
+                    for (;;) {
+                        depth++;
+                        Hit is;
+                        rays++;
+                        if (!intersect_scene(sc.sp, sc.ns, org, dir, is)) break;
+                        const sppm_sphere* obj = &sc.sp[is.object_id];
+                        const d3 color = ld3(obj->color);
+                        const int type = obj->reflection_type;
+                        const d3 on = dot(is.normal, dir) < 0.0 ? is.normal : is.normal * -1.0;
+                        if (direct) ld = ld + had(weight, ld3(obj->emission));
+                        direct = type != SPPM_DIFFUSE;
+                        if (type == SPPM_DIFFUSE) {
+                            const d3 est = next_event_est(sc.sp, sc.ns, is, on, rng, rays);
+                            ld = ld + had(weight, est);
+                            // create or overwrite the pixel's hitpoint (src/sppm2.h:204-227)
+                            hp.pos[index] = is.position.x; hp.pos[P + index] = is.position.y; hp.pos[2 * P + index] = is.position.z;
+                            hp.nrm[index] = is.normal.x; hp.nrm[P + index] = is.normal.y; hp.nrm[2 * P + index] = is.normal.z;
+                            hp.w[index] = weight.x; hp.w[P + index] = weight.y; hp.w[2 * P + index] = weight.z;
+                            hp.obj[index] = is.object_id; hp.dist[index] = is.distance;
+                            if (!valid) {
+                                valid = 1;
+                                hp.valid[index] = 1;
+                                hp.r2[index] = ep.initial_r2;
+                                hp.n[index] = 0;  // the reference leaves photon_count unset (src/sppm2.h:108-116); its call site passes 0
+                                hp.flux[index] = 0.0; hp.flux[P + index] = 0.0; hp.flux[2 * P + index] = 0.0;
+                                if (hp.nd) {
+                                    hp.nd[index] = 0.0; hp.madd[index] = 0;
+                                    hp.phi[index] = 0.0; hp.phi[P + index] = 0.0; hp.phi[2 * P + index] = 0.0;
+                                    hp.tau[index] = 0.0; hp.tau[P + index] = 0.0; hp.tau[2 * P + index] = 0.0;
+                                }
+                                // the reference's `break` leaves the switch only: fall into the roulette
+                                // block and go round again with the same ray (second direct sample)
+                                if (!ep.double_nee) goto path_done;
+                            } else
+                                goto path_done;
+                        } else if (type == SPPM_SPECULAR) {
+                            org = is.position;
+                            dir = reflect_dir(dir, is.normal);
+                            weight = had(weight, color);
+                        } else {
+                            const d3 rdir = reflect_dir(dir, is.normal);
+                            bool into; double nnt, Re; d3 tdir;
+                            org = is.position;
+                            if (!glass(dir, is.normal, on, true, into, nnt, tdir, Re)) {
+                                dir = rdir;
+                                weight = had(weight, color);
+                            } else {
+                                const double nnt2 = nnt * nnt;
+                                const double Tr = (1.0 - Re) * nnt2;
+                                const double prob = 0.25 + 0.5 * Re;
+                                if (rng.next01() < prob) {
+                                    dir = rdir;
+                                    weight = had(weight, color * Re / prob);
+                                } else {
+                                    dir = tdir;
+                                    weight = had(weight, color * Tr / (1.0 - prob));
+                                }
+                            }
+                        }
+                        {   // Russian roulette, src/sppm2.h:298-313
+                            double rr = max3(color);
+                            if (depth >= SPPM_KDEPTH) {
+                                rr *= ldexp(1.0, -(depth - SPPM_KDEPTH));  // std::pow(0.5, depth - MaxDepth)
+                                if (rng.next01() >= rr) break;
+                            } else
+                                rr = 1.0;
+                            weight = weight / rr;
+                        }
+                    }
+                path_done:;
+                }
+        hp.ld[index] = ld.x; hp.ld[P + index] = ld.y; hp.ld[2 * P + index] = ld.z;
+    }
+    // rays counter: one atomic per wave
+    for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off);
+    if ((threadIdx.x & 63) == 0 && rays) atomicAdd(&counters[0], (unsigned long long)rays);
+}
+
+struct TraceParams {
+    int pass; int64_t first, count, photons_per_pass; uint32_t seed_photon; double flux_scale;
+    int64_t rec_cap;
+};
+struct RecArrays { uint64_t* key; double* f; int64_t cap; };  // f[9][cap]
+
+// One thread per photon: create_photon, src/sppm2.h:317-525, with the kd search + update replaced
+// by appending a photon-hit record (diffuse hit, depth > 0).
+__global__ void __launch_bounds__(256) k_photon_trace(DevScene sc, TraceParams tp, RecArrays rec, unsigned long long* __restrict__ rec_count,
+                                                      unsigned long long* __restrict__ counters, int32_t* __restrict__ err)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t rays = 0;
+    if (t < tp.count) {
+        const int64_t i = tp.first + t;
+        XorShift rng = make_stream(tp.seed_photon, (uint64_t)tp.pass * (uint64_t)tp.photons_per_pass + (uint64_t)i);
+        (void)rng.next01(); (void)rng.next01();  // two draws computed and discarded, src/sppm2.h:322-324
+        const double r1 = 2 * SPPM_PI * rng.next01();
+        const double r2 = 1.0 - 2.0 * rng.next01();
+        const double r3 = 1.0 - r2 * r2;
+        double sn, cs;
+        dm_sincos(r1, &sn, &cs);
+        const d3 lc = ld3(sc.sp[0].position);
+        const d3 source_pos = lc + mk(sqrt(r3) * cs, sqrt(r3) * sn, r2) * (sc.sp[0].radius + SPPM_EPS);
+        const d3 w = normalize(source_pos - lc);
+        d3 u, v;
+        basis(w, u, v);
+        d3 org = source_pos;
+        d3 dir = cosine_sampling(w, u, v, rng);
+        d3 flux = ld3(sc.sp[0].emission) * 4.0 * tp.flux_scale;
+        int depth = -1;
+        for (;;) {
+            if (max3(flux) <= 0.0) break;
+            Hit is;
+            rays++;
+            if (!intersect_scene(sc.sp, sc.ns, org, dir, is)) break;
+            const sppm_sphere* obj = &sc.sp[is.object_id];
+            const d3 color = ld3(obj->color);
+            const int type = obj->reflection_type;
+            const bool flip = !(dot(is.normal, dir) < 0.0);
+            const d3 on = flip ? is.normal * -1.0 : is.normal;
+            depth++;
+            if (type == SPPM_DIFFUSE) {
+                if (depth > 0) {
+                    if (depth > 32767) { err[1] = 1; break; }
+                    const unsigned long long slot = atomicAdd(rec_count, 1ull);
+                    if ((int64_t)slot < rec.cap) {
+                        rec.key[slot] = ((uint64_t)i << 16) | ((uint64_t)depth << 1) | (flip ? 1ull : 0ull);
+                        double* f = rec.f + slot;
+                        const int64_t c = rec.cap;
+                        f[0] = is.position.x; f[c] = is.position.y; f[2 * c] = is.position.z;
+                        f[3 * c] = is.normal.x; f[4 * c] = is.normal.y; f[5 * c] = is.normal.z;
+                        f[6 * c] = flux.x; f[7 * c] = flux.y; f[8 * c] = flux.z;
+                    } else
+                        err[0] = 1;
+                }
+                const double prob = (color.x + color.y + color.z) / 3;
+                if (prob > rng.next01()) {
+                    d3 du, dv;
+                    basis(on, du, dv);
+                    dir = cosine_sampling(on, du, dv, rng);
+                    org = is.position;
+                    flux = had(flux, color) / prob;
+                } else
+                    break;
+            } else if (type == SPPM_SPECULAR) {
+                dir = reflect_dir(dir, is.normal);
+                org = is.position;
+                flux = had(flux, color);
+            } else {
+                const d3 rdir = reflect_dir(dir, is.normal);
+                bool into; double nnt, Re; d3 tdir;
+                org = is.position;
+                if (!glass(dir, is.normal, on, false, into, nnt, tdir, Re)) {
+                    dir = rdir;
+                } else {
+                    dir = (rng.next01() < Re) ? rdir : tdir;
+                }
+                flux = had(flux, color);
+            }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off);
+    if ((threadIdx.x & 63) == 0 && rays) atomicAdd(&counters[0], (unsigned long long)rays);
+}
+
+// ---- hash grid over the records of a batch ----------------------------------------------------------
+struct Grid { double inv_cell; uint32_t mask; };
+
+__device__ __forceinline__ int cell_coord(double x, double inv_cell) { return (int)floor(x * inv_cell); }
+__device__ __forceinline__ uint32_t cell_hash(int ix, int iy, int iz, uint32_t mask)
+{
+    return (((uint32_t)ix * 73856093u) ^ ((uint32_t)iy * 19349663u) ^ ((uint32_t)iz * 83492791u)) & mask;
+}
+
+__global__ void k_grid_count(RecArrays rec, const unsigned long long* __restrict__ rec_count, Grid g, uint32_t* __restrict__ cell_cnt,
+                             uint32_t* __restrict__ rec_bucket)
+{
+    const int64_t n = min((int64_t)*rec_count, rec.cap);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t b = cell_hash(cell_coord(rec.f[i], g.inv_cell), cell_coord(rec.f[rec.cap + i], g.inv_cell),
+                                     cell_coord(rec.f[2 * rec.cap + i], g.inv_cell), g.mask);
+        rec_bucket[i] = b;
+        atomicAdd(&cell_cnt[b], 1u);
+    }
+}
+
+// exclusive scan of cell_cnt[0..n) -> cell_start[0..n], three small kernels (n is a power of two >= 1024)
+#define SCAN_BLOCK 1024
+__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_blocks(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t* __restrict__ block_sum)
+{
+    __shared__ uint32_t wave_tot[SCAN_BLOCK / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const size_t i = (size_t)blockIdx.x * SCAN_BLOCK + tid;
+    const uint32_t v = in[i];
+    uint32_t x = v;
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t y = __shfl_up(x, off); if (lane >= off) x += y; }
+    if (lane == 63) wave_tot[wv] = x;
+    __syncthreads();
+    if (wv == 0) {
+        uint32_t t = lane < SCAN_BLOCK / 64 ? wave_tot[lane] : 0;
+        for (int off = 1; off < SCAN_BLOCK / 64; off <<= 1) { const uint32_t y = __shfl_up(t, off); if (lane >= off) t += y; }
+        if (lane < SCAN_BLOCK / 64) wave_tot[lane] = t;
+    }
+    __syncthreads();
+    const uint32_t base = wv ? wave_tot[wv - 1] : 0;
+    out[i] = base + x - v;
+    if (tid == SCAN_BLOCK - 1) block_sum[blockIdx.x] = base + x;
+}
+__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_tops(uint32_t* __restrict__ block_sum, int nblocks, uint32_t* __restrict__ total_out)
+{
+    // single block; nblocks <= 16384 handled by a serial carry over chunks of SCAN_BLOCK
+    __shared__ uint32_t wave_tot[SCAN_BLOCK / 64];
+    __shared__ uint32_t carry;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int base_i = 0; base_i < nblocks; base_i += SCAN_BLOCK) {
+        const int i = base_i + tid;
+        const uint32_t v = i < nblocks ? block_sum[i] : 0;
+        uint32_t x = v;
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t y = __shfl_up(x, off); if (lane >= off) x += y; }
+        if (lane == 63) wave_tot[wv] = x;
+        __syncthreads();
+        if (wv == 0) {
+            uint32_t t = lane < SCAN_BLOCK / 64 ? wave_tot[lane] : 0;
+            for (int off = 1; off < SCAN_BLOCK / 64; off <<= 1) { const uint32_t y = __shfl_up(t, off); if (lane >= off) t += y; }
+            if (lane < SCAN_BLOCK / 64) wave_tot[lane] = t;
+        }
+        __syncthreads();
+        const uint32_t b = carry + (wv ? wave_tot[wv - 1] : 0);
+        if (i < nblocks) block_sum[i] = b + x - v;
+        __syncthreads();
+        if (tid == SCAN_BLOCK - 1) carry = b + x;
+        __syncthreads();
+    }
+    if (tid == 0) *total_out = carry;
+}
+__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_add(uint32_t* __restrict__ out, const uint32_t* __restrict__ block_sum, uint32_t* __restrict__ cursor,
+                                                         size_t n, const uint32_t* __restrict__ total)
+{
+    const size_t i = (size_t)blockIdx.x * SCAN_BLOCK + threadIdx.x;
+    const uint32_t v = out[i] + block_sum[blockIdx.x];
+    out[i] = v;
+    cursor[i] = v;
+    if (i == n - 1) out[n] = *total;
+}
+__global__ void k_grid_scatter(RecArrays src, RecArrays dst, const unsigned long long* __restrict__ rec_count,
+                               const uint32_t* __restrict__ rec_bucket, uint32_t* __restrict__ cursor)
+{
+    const int64_t n = min((int64_t)*rec_count, src.cap);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t p = atomicAdd(&cursor[rec_bucket[i]], 1u);
+        dst.key[p] = src.key[i];
+#pragma unroll
+        for (int c = 0; c < 9; c++) dst.f[c * dst.cap + p] = src.f[c * src.cap + i];
+    }
+}
+
+// max over valid hitpoints of min(r2, gather_r2), as an ordered-int atomic max on the bit pattern
+__global__ void k_r2max(HpArrays hp, int first, int count, double gather_r2, unsigned long long* __restrict__ out)
+{
+    double m = 0.0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+        const int p = first + i;
+        if (hp.valid[p]) { const double r = fmin(hp.r2[p], gather_r2); m = fmax(m, r); }
+    }
+    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_down(m, off));
+    if ((threadIdx.x & 63) == 0 && m > 0.0) atomicMax(out, (unsigned long long)__double_as_longlong(m));
+}
+
+// ---- gather: each hitpoint replays the records near it in key order ------------------------------------
+struct GatherParams {
+    Grid g; double gather_r2, alpha; int rule; int first, count;
+    uint64_t* tap_key; int32_t* tap_pix; unsigned long long* tap_n; int64_t tap_cap;
+};
+
+#define SEL 8  // keys selected per scan of the neighbourhood
+
+// Does record r pass the search filter of src/kdtree.h:123-127 and the acceptance test of
+// src/sppm2.h:393-395 for a hitpoint at hpos with normal hn and squared radius r2?
+__device__ __forceinline__ bool rec_accept(const RecArrays& rec, int64_t r, uint64_t key, d3 hpos, d3 hn, double r2, double gather_r2)
+{
+    const int64_t c = rec.cap;
+    const d3 q = mk(rec.f[r], rec.f[c + r], rec.f[2 * c + r]);
+    const d3 dir = hpos - q;  // node position - search position, kdtree.h:123
+    const double d2 = len2(dir);
+    if (!(d2 < gather_r2) || !(d2 <= r2)) return false;
+    const d3 gn = mk(rec.f[3 * c + r], rec.f[4 * c + r], rec.f[5 * c + r]);
+    if (!(dot(hn, gn) > 1e-3)) return false;
+    const d3 on = (key & 1ull) ? gn * -1.0 : gn;
+    const double dt = dot(on, dir / sqrt(d2));           // NaN when d2 == 0: rejected, as in the reference
+    return fabs(dt) <= gather_r2 * 0.01;
+}
+
+__global__ void __launch_bounds__(256) k_gather(HpArrays hp, DevScene sc, RecArrays rec, const uint32_t* __restrict__ cell_start, GatherParams gp,
+                                                unsigned long long* __restrict__ counters)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t n_cand = 0, n_acc = 0;
+    if (t < gp.count) {
+        const int p = gp.first + t;
+        const int P = hp.P;
+        if (hp.valid[p]) {
+            const d3 hpos = mk(hp.pos[p], hp.pos[P + p], hp.pos[2 * P + p]);
+            const d3 hn = mk(hp.nrm[p], hp.nrm[P + p], hp.nrm[2 * P + p]);
+            const d3 hw = mk(hp.w[p], hp.w[P + p], hp.w[2 * P + p]);
+            const d3 hcol = ld3(sc.sp[hp.obj[p]].color);
+            double r2 = hp.r2[p];
+            int n = 0; double nd = 0.0; int madd = 0;
+            d3 acc;
+            if (gp.rule == 0) { n = hp.n[p]; acc = mk(hp.flux[p], hp.flux[P + p], hp.flux[2 * P + p]); }
+            else { madd = hp.madd[p]; acc = mk(hp.phi[p], hp.phi[P + p], hp.phi[2 * P + p]); }
+            // cells overlapping the sphere of the larger of the two bounds the tests use
+            const double rr = sqrt(fmin(r2, gp.gather_r2)) * (1.0 + 1e-9) + 1e-12;
+            const int x0 = cell_coord(hpos.x - rr, gp.g.inv_cell), x1 = cell_coord(hpos.x + rr, gp.g.inv_cell);
+            const int y0 = cell_coord(hpos.y - rr, gp.g.inv_cell), y1 = cell_coord(hpos.y + rr, gp.g.inv_cell);
+            const int z0 = cell_coord(hpos.z - rr, gp.g.inv_cell), z1 = cell_coord(hpos.z + rr, gp.g.inv_cell);
+            uint64_t last = 0;  // keys are > 0: depth >= 1
+            for (;;) {
+                // select the SEL smallest keys > last among accepted candidates (sorted ascending)
+                uint64_t sk[SEL]; int64_t si[SEL];
+#pragma unroll
+                for (int j = 0; j < SEL; j++) { sk[j] = ~0ull; si[j] = -1; }
+                for (int iz = z0; iz <= z1; iz++)
+                    for (int iy = y0; iy <= y1; iy++)
+                        for (int ix = x0; ix <= x1; ix++) {
+                            const uint32_t b = cell_hash(ix, iy, iz, gp.g.mask);
+                            const uint32_t e = cell_start[b + 1];
+                            for (uint32_t r = cell_start[b]; r < e; r++) {
+                                const uint64_t key = rec.key[r];
+                                if (last == 0) n_cand++;
+                                if (key <= last || key >= sk[SEL - 1]) continue;
+                                if (!rec_accept(rec, r, key, hpos, hn, r2, gp.gather_r2)) continue;
+                                // two cells of the range may share a bucket: skip a key already held
+                                bool dup = false;
+#pragma unroll
+                                for (int j = 0; j < SEL; j++) dup |= (sk[j] == key);
+                                if (dup) continue;
+                                uint64_t ck = key; int64_t ci = r;
+#pragma unroll
+                                for (int j = 0; j < SEL; j++) {
+                                    if (ck < sk[j]) { const uint64_t tk = sk[j]; const int64_t ti = si[j]; sk[j] = ck; si[j] = ci; ck = tk; ci = ti; }
+                                }
+                            }
+                        }
+                if (si[0] < 0) break;
+#pragma unroll
+                for (int j = 0; j < SEL; j++) {
+                    if (si[j] < 0) continue;
+                    const int64_t r = si[j];
+                    last = sk[j];
+                    // the radius may have shrunk since the scan: test again with the current one
+                    if (!rec_accept(rec, r, sk[j], hpos, hn, r2, gp.gather_r2)) continue;
+                    const int64_t c = rec.cap;
+                    const d3 pf = mk(rec.f[6 * c + r], rec.f[7 * c + r], rec.f[8 * c + r]);
+                    if (gp.rule == 0) {  // src/sppm2.h:397-419
+                        double g;
+                        if (n != 0) g = (n * gp.alpha + gp.alpha) / (n * gp.alpha + 1.0);
+                        else g = 1;
+                        r2 = r2 * g;
+                        n++;
+                        acc = (acc + had(hw, had(hcol, pf)) / SPPM_PI) * g;
+                    } else {             // src/stochastic_ppm.h:449-454
+                        const d3 f = hcol / SPPM_PI;
+                        acc = acc + had(pf, f);
+                        madd++;
+                    }
+                    n_acc++;
+                    if (gp.tap_cap > 0) {
+                        const unsigned long long slot = atomicAdd(gp.tap_n, 1ull);
+                        if ((int64_t)slot < gp.tap_cap) { gp.tap_key[slot] = sk[j]; gp.tap_pix[slot] = p; }
+                    }
+                }
+                if (si[SEL - 1] < 0) break;  // the scan found fewer than SEL: nothing is left
+            }
+            if (gp.rule == 0) {
+                hp.r2[p] = r2; hp.n[p] = n;
+                hp.flux[p] = acc.x; hp.flux[P + p] = acc.y; hp.flux[2 * P + p] = acc.z;
+            } else {
+                hp.madd[p] = madd;
+                hp.phi[p] = acc.x; hp.phi[P + p] = acc.y; hp.phi[2 * P + p] = acc.z;
+            }
+            (void)nd;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) { n_cand += __shfl_down(n_cand, off); n_acc += __shfl_down(n_acc, off); }
+    if ((threadIdx.x & 63) == 0) {
+        if (n_cand) atomicAdd(&counters[3], (unsigned long long)n_cand);
+        if (n_acc) atomicAdd(&counters[4], (unsigned long long)n_acc);
+    }
+}
+
+// end-of-pass update of rule 1, src/stochastic_ppm.h:721-741
+__global__ void k_end_pass(HpArrays hp, int first, int count, double alpha)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    const int p = first + t, P = hp.P;
+    if (!hp.valid[p]) return;
+    const int madd = hp.madd[p];
+    if (madd > 0) {
+        const double N = hp.nd[p], r2 = hp.r2[p];
+        const double Nnew = N + alpha * madd;
+        const double Rnew2 = r2 * Nnew / (N + madd);
+        const d3 tau = mk(hp.tau[p], hp.tau[P + p], hp.tau[2 * P + p]);
+        const d3 phi = mk(hp.phi[p], hp.phi[P + p], hp.phi[2 * P + p]);
+        const d3 w = mk(hp.w[p], hp.w[P + p], hp.w[2 * P + p]);
+        const d3 tn = (tau + had(phi, w)) * Rnew2 / r2;
+        hp.tau[p] = tn.x; hp.tau[P + p] = tn.y; hp.tau[2 * P + p] = tn.z;
+        hp.nd[p] = Nnew; hp.r2[p] = Rnew2; hp.madd[p] = 0;
+        hp.phi[p] = 0.0; hp.phi[P + p] = 0.0; hp.phi[2 * P + p] = 0.0;
+    }
+    hp.w[p] = 0.0; hp.w[P + p] = 0.0; hp.w[2 * P + p] = 0.0;
+}
+
+// image assembly, src/sppm2.h:658-670 (rule 0) / src/stochastic_ppm.h:743-765 (rule 1)
+__global__ void k_resolve(HpArrays hp, int pass, int64_t photon_num, int rule, double* __restrict__ image)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int P = hp.P;
+    if (i >= P) return;
+    d3 c = mk(hp.ld[i], hp.ld[P + i], hp.ld[2 * P + i]) / (double)(pass + 1);
+    if (hp.valid[i]) {
+        if (rule == 0)
+            c = c + mk(hp.flux[i], hp.flux[P + i], hp.flux[2 * P + i]) * (1.0 / (SPPM_PI * hp.r2[i] * (pass + 1) * (double)photon_num));
+        else
+            c = c + mk(hp.tau[i], hp.tau[P + i], hp.tau[2 * P + i]) * (1.0 / (SPPM_PI * hp.r2[i] * (double)((int64_t)(pass + 1) * photon_num)));
+    }
+    image[3 * (size_t)i] = c.x; image[3 * (size_t)i + 1] = c.y; image[3 * (size_t)i + 2] = c.z;
+}
+
+// get_hdr_pixel, src/hdr.h:37-45
+__device__ __host__ inline void hdr_pixel(double x, double y, double z, uint8_t* out)
+{
+    const double m0 = y > z ? y : z;
+    double d = x > m0 ? x : m0;
+    if (d <= 1e-32) { out[0] = out[1] = out[2] = out[3] = 0; return; }
+    int e;
+    const double m = frexp(d, &e);
+    d = m * 256.0 / d;
+    out[0] = (uint8_t)(int)(x * d); out[1] = (uint8_t)(int)(y * d); out[2] = (uint8_t)(int)(z * d); out[3] = (uint8_t)(e + 128);
+}
+__global__ void k_hdr_pixels(const double* __restrict__ rgb, int64_t n, uint8_t* __restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint8_t px[4];
+    hdr_pixel(rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2], px);
+    out[4 * i] = px[0]; out[4 * i + 1] = px[1]; out[4 * i + 2] = px[2]; out[4 * i + 3] = px[3];
+}
+
+// ================================ host side / C ABI =================================================
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) return fail(SPPM_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+struct sppm_ctx {
+    sppm_config cfg;
+    int device;
+    hipStream_t stream;
+    int P;
+    int pix_first, pix_count;
+    sppm_sphere* d_spheres; int ns;
+    Camera cam;
+    double flux_scale;
+    std::vector<void*> allocs;
+    HpArrays hp;
+    RecArrays rec_u, rec_s;  // unsorted (traced / received), sorted by bucket
+    unsigned long long* d_rec_count;
+    unsigned long long* d_counters;  // 8
+    unsigned long long* d_r2max;
+    int32_t* d_err;                  // 4
+    uint32_t *d_cell_cnt, *d_cell_start, *d_cursor, *d_block_sum, *d_total, *d_rec_bucket;
+    uint32_t n_buckets;
+    int64_t batch_photons;
+    // accept tap
+    uint64_t* d_tap_key; int32_t* d_tap_pix; unsigned long long* d_tap_n; int64_t tap_cap;
+    // timing of the gather kernel
+    int timing;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+    uint64_t gather_ns, gather_launches, gather_batches;
+    uint64_t photons_traced, records_total;
+};
+
+template <typename T>
+static int dev_alloc(sppm_ctx* c, T** p, size_t n, bool zero = true)
+{
+    void* q = nullptr;
+    HIPCHK(hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T)));
+    c->allocs.push_back(q);
+    if (zero) HIPCHK(hipMemsetAsync(q, 0, std::max<size_t>(n, 1) * sizeof(T), c->stream));
+    *p = (T*)q;
+    return 0;
+}
+
+static void host_normalize(const double* v, double* o)
+{
+    const double inv = 1.0 / std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    o[0] = v[0] * inv; o[1] = v[1] * inv; o[2] = v[2] * inv;
+}
+static void host_cross(const double* a, const double* b, double* o)
+{
+    o[0] = (a[1] * b[2]) - (a[2] * b[1]); o[1] = (a[2] * b[0]) - (a[0] * b[2]); o[2] = (a[0] * b[1]) - (a[1] * b[0]);
+}
+
+extern "C" const char* sppm_last_error(void) { return g_err.c_str(); }
+
+extern "C" int sppm_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+static int64_t env_i64(const char* name, int64_t dflt)
+{
+    const char* s = getenv(name);
+    return (s && *s) ? atoll(s) : dflt;
+}
+
+extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres, int32_t n_spheres, void* stream, sppm_ctx** out)
+{
+    if (!cfg || !h_spheres || !out || n_spheres < 1) return fail(SPPM_ERR_INVALID, "sppm_create: null argument or empty scene");
+    if (cfg->width < 1 || cfg->height < 1 || cfg->samples < 1 || cfg->supersamples < 1)
+        return fail(SPPM_ERR_INVALID, "sppm_create: width, height, samples, supersamples must be >= 1");
+    if ((int64_t)cfg->width * cfg->height > (1ll << 30)) return fail(SPPM_ERR_INVALID, "sppm_create: image too large");
+    if (!(cfg->gather_radius2 > 0.0) || !(cfg->initial_radius2 > 0.0) || !(cfg->alpha > 0.0))
+        return fail(SPPM_ERR_INVALID, "sppm_create: radii and alpha must be positive");
+    if (cfg->update_rule != 0 && cfg->update_rule != 1) return fail(SPPM_ERR_INVALID, "sppm_create: update_rule must be 0 or 1");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(SPPM_ERR_HIP, "sppm_create: no HIP device (this library has no CPU path)");
+    sppm_ctx* c = new sppm_ctx();
+    c->cfg = *cfg;
+    c->stream = (hipStream_t)stream;
+    c->P = cfg->width * cfg->height;
+    c->pix_first = cfg->pixel_count > 0 ? cfg->pixel_first : 0;
+    c->pix_count = cfg->pixel_count > 0 ? cfg->pixel_count : c->P;
+    if (c->pix_first < 0 || c->pix_first + c->pix_count > c->P) { delete c; return fail(SPPM_ERR_INVALID, "sppm_create: pixel slice out of range"); }
+    c->ns = n_spheres;
+    c->tap_cap = 0; c->d_tap_key = nullptr; c->d_tap_pix = nullptr; c->d_tap_n = nullptr;
+    c->timing = 0; c->gather_ns = c->gather_launches = c->gather_batches = 0; c->photons_traced = c->records_total = 0;
+    int rc = 0;
+#define TRY(x) do { rc = (x); if (rc) { sppm_destroy(c); return rc; } } while (0)
+    if (hipGetDevice(&c->device) != hipSuccess) { delete c; return fail(SPPM_ERR_HIP, "hipGetDevice failed"); }
+    TRY(dev_alloc(c, &c->d_spheres, (size_t)n_spheres, false));
+    if (hipMemcpyAsync(c->d_spheres, h_spheres, sizeof(sppm_sphere) * (size_t)n_spheres, hipMemcpyHostToDevice, c->stream) != hipSuccess) {
+        sppm_destroy(c); return fail(SPPM_ERR_HIP, "copying the scene failed");
+    }
+    {   // PinholeCamera constructor, src/cameras.h:34-50
+        double sxn[3], cx[3], sx[3], sy[3], cy[3], syn[3], center[3];
+        const double screen_width = cfg->screen_height * (double)cfg->width / (double)cfg->height;
+        host_cross(cfg->camera_dir, cfg->camera_up, cx); host_normalize(cx, sxn);
+        for (int k = 0; k < 3; k++) sx[k] = sxn[k] * screen_width;
+        host_cross(sx, cfg->camera_dir, cy); host_normalize(cy, syn);
+        for (int k = 0; k < 3; k++) sy[k] = syn[k] * cfg->screen_height;
+        for (int k = 0; k < 3; k++) center[k] = cfg->camera_position[k] + cfg->camera_dir[k] * cfg->screen_dist;
+        c->cam = make_camera_fields(cfg->camera_position, sx, sy, center, (double)cfg->width, (double)cfg->height, (double)cfg->supersamples);
+    }
+    {   // std::pow(light.radius * M_PI, 2.0), src/sppm2.h:348
+        const double rp = h_spheres[0].radius * SPPM_PI;
+        c->flux_scale = rp * rp;
+    }
+    const size_t P = (size_t)c->P;
+    c->hp.P = c->P;
+    TRY(dev_alloc(c, &c->hp.pos, 3 * P)); TRY(dev_alloc(c, &c->hp.nrm, 3 * P)); TRY(dev_alloc(c, &c->hp.w, 3 * P));
+    TRY(dev_alloc(c, &c->hp.flux, 3 * P)); TRY(dev_alloc(c, &c->hp.ld, 3 * P));
+    TRY(dev_alloc(c, &c->hp.r2, P)); TRY(dev_alloc(c, &c->hp.dist, P));
+    TRY(dev_alloc(c, &c->hp.n, P)); TRY(dev_alloc(c, &c->hp.obj, P)); TRY(dev_alloc(c, &c->hp.valid, P));
+    if (cfg->update_rule == 1) {
+        TRY(dev_alloc(c, &c->hp.phi, 3 * P)); TRY(dev_alloc(c, &c->hp.tau, 3 * P)); TRY(dev_alloc(c, &c->hp.nd, P)); TRY(dev_alloc(c, &c->hp.madd, P));
+    } else { c->hp.phi = c->hp.tau = c->hp.nd = nullptr; c->hp.madd = nullptr; }
+    // record buffers: one batch of photons, ~2.6 records per photon on the Cornell scene; 8x head room
+    c->batch_photons = env_i64("SPPM_BATCH_PHOTONS", 1 << 18);
+    if (c->batch_photons < 1024) c->batch_photons = 1024;
+    const int64_t cap = env_i64("SPPM_RECORD_CAP", c->batch_photons * 8);
+    c->rec_u.cap = c->rec_s.cap = cap;
+    TRY(dev_alloc(c, &c->rec_u.key, (size_t)cap, false)); TRY(dev_alloc(c, &c->rec_u.f, 9 * (size_t)cap, false));
+    TRY(dev_alloc(c, &c->rec_s.key, (size_t)cap, false)); TRY(dev_alloc(c, &c->rec_s.f, 9 * (size_t)cap, false));
+    TRY(dev_alloc(c, &c->d_rec_bucket, (size_t)cap, false));
+    uint32_t nb = 1024;
+    while ((int64_t)nb < cap / 2 && nb < (1u << 24)) nb <<= 1;
+    c->n_buckets = nb;
+    TRY(dev_alloc(c, &c->d_cell_cnt, (size_t)nb)); TRY(dev_alloc(c, &c->d_cell_start, (size_t)nb + 1)); TRY(dev_alloc(c, &c->d_cursor, (size_t)nb));
+    TRY(dev_alloc(c, &c->d_block_sum, (size_t)nb / SCAN_BLOCK + 1)); TRY(dev_alloc(c, &c->d_total, 1));
+    TRY(dev_alloc(c, &c->d_rec_count, 1)); TRY(dev_alloc(c, &c->d_counters, 8)); TRY(dev_alloc(c, &c->d_r2max, 1)); TRY(dev_alloc(c, &c->d_err, 4));
+#undef TRY
+    if (hipStreamSynchronize(c->stream) != hipSuccess) { sppm_destroy(c); return fail(SPPM_ERR_HIP, "sppm_create: stream sync failed"); }
+    *out = c;
+    return SPPM_OK;
+}
+
+extern "C" int sppm_destroy(sppm_ctx* c)
+{
+    if (!c) return SPPM_OK;
+    hipStreamSynchronize(c->stream);
+    for (auto& e : c->ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    for (void* p : c->allocs) hipFree(p);
+    delete c;
+    return SPPM_OK;
+}
+
+static inline DevScene scene_of(const sppm_ctx* c) { DevScene s; s.sp = c->d_spheres; s.ns = c->ns; return s; }
+static inline int nblk(int64_t n, int b) { return (int)((n + b - 1) / b); }
+
+extern "C" int sppm_camera_rays(sppm_ctx* c, int32_t sx, int32_t sy, double* d_rays)
+{
+    if (!c || !d_rays) return fail(SPPM_ERR_INVALID, "sppm_camera_rays: null argument");
+    hipLaunchKernelGGL(k_camera_rays, dim3(nblk(c->P, 256)), dim3(256), 0, c->stream, c->cam, c->cfg.width, c->cfg.height, sx, sy, d_rays);
+    HIPCHK(hipGetLastError());
+    return SPPM_OK;
+}
+
+extern "C" int sppm_intersect(sppm_ctx* c, const double* d_rays, int64_t n, int32_t* d_id, double* d_hit)
+{
+    if (!c || n < 0 || (n > 0 && (!d_rays || !d_id || !d_hit))) return fail(SPPM_ERR_INVALID, "sppm_intersect: bad argument");
+    if (n == 0) return SPPM_OK;
+    hipLaunchKernelGGL(k_intersect, dim3(nblk(n, 256)), dim3(256), 0, c->stream, scene_of(c), d_rays, n, d_id, d_hit);
+    HIPCHK(hipGetLastError());
+    return SPPM_OK;
+}
+
+extern "C" int sppm_eye_pass(sppm_ctx* c, int32_t pass)
+{
+    if (!c || pass < 0) return fail(SPPM_ERR_INVALID, "sppm_eye_pass: bad argument");
+    EyeParams ep;
+    ep.cam = c->cam; ep.W = c->cfg.width; ep.H = c->cfg.height; ep.samples = c->cfg.samples; ep.supersamples = c->cfg.supersamples;
+    ep.pass = pass; ep.seed_eye = c->cfg.seed_eye; ep.initial_r2 = c->cfg.initial_radius2; ep.double_nee = c->cfg.double_nee;
+    hipLaunchKernelGGL(k_eye_pass, dim3(nblk(c->P, 256)), dim3(256), 0, c->stream, scene_of(c), ep, c->hp, c->d_counters);
+    HIPCHK(hipGetLastError());
+    return SPPM_OK;
+}
+
+extern "C" int sppm_trace(sppm_ctx* c, int32_t pass, int64_t first, int64_t count)
+{
+    if (!c || pass < 0 || first < 0 || count < 0) return fail(SPPM_ERR_INVALID, "sppm_trace: bad argument");
+    if (c->cfg.photons_per_pass > 0 && first + count > c->cfg.photons_per_pass)
+        return fail(SPPM_ERR_INVALID, "sppm_trace: photon range exceeds photons_per_pass");
+    if (count == 0) return SPPM_OK;
+    TraceParams tp;
+    tp.pass = pass; tp.first = first; tp.count = count;
+    tp.photons_per_pass = c->cfg.photons_per_pass; tp.seed_photon = c->cfg.seed_photon; tp.flux_scale = c->flux_scale; tp.rec_cap = c->rec_u.cap;
+    hipLaunchKernelGGL(k_photon_trace, dim3(nblk(count, 256)), dim3(256), 0, c->stream, scene_of(c), tp, c->rec_u, c->d_rec_count, c->d_counters, c->d_err);
+    HIPCHK(hipGetLastError());
+    c->photons_traced += (uint64_t)count;
+    return SPPM_OK;
+}
+
+extern "C" int sppm_records(sppm_ctx* c, uint64_t** d_key, double** d_f, int64_t* n, int64_t* cap)
+{
+    if (!c) return fail(SPPM_ERR_INVALID, "sppm_records: null context");
+    if (n) {
+        unsigned long long cnt = 0;
+        HIPCHK(hipMemcpyAsync(&cnt, c->d_rec_count, sizeof cnt, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if ((int64_t)cnt > c->rec_u.cap) return fail(SPPM_ERR_OVERFLOW, "record buffer overflow: raise SPPM_RECORD_CAP or lower SPPM_BATCH_PHOTONS");
+        *n = (int64_t)cnt;
+    }
+    if (d_key) *d_key = c->rec_u.key;
+    if (d_f) *d_f = c->rec_u.f;
+    if (cap) *cap = c->rec_u.cap;
+    return SPPM_OK;
+}
+
+extern "C" int sppm_set_record_count(sppm_ctx* c, int64_t n)
+{
+    if (!c || n < 0 || n > c->rec_u.cap) return fail(SPPM_ERR_INVALID, "sppm_set_record_count: count out of range");
+    const unsigned long long v = (unsigned long long)n;
+    HIPCHK(hipMemcpyAsync(c->d_rec_count, &v, sizeof v, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return SPPM_OK;
+}
+
+// grid build + ordered gather over whatever is in the unsorted record buffer; clears the buffer
+extern "C" int sppm_gather(sppm_ctx* c)
+{
+    if (!c) return fail(SPPM_ERR_INVALID, "sppm_gather: null context");
+    hipStream_t st = c->stream;
+    const uint32_t nb = c->n_buckets;
+    // cell size = sqrt of the largest squared bound any of this rank's hitpoints uses
+    HIPCHK(hipMemsetAsync(c->d_r2max, 0, sizeof(unsigned long long), st));
+    hipLaunchKernelGGL(k_r2max, dim3(std::min(nblk(c->pix_count, 256), 2048)), dim3(256), 0, st, c->hp, c->pix_first, c->pix_count, c->cfg.gather_radius2, c->d_r2max);
+    unsigned long long bits = 0;
+    HIPCHK(hipMemcpyAsync(&bits, c->d_r2max, sizeof bits, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    double r2max;
+    memcpy(&r2max, &bits, 8);
+    if (!(r2max > 0.0)) {  // no valid hitpoint on this rank: nothing can be accepted
+        HIPCHK(hipMemsetAsync(c->d_rec_count, 0, sizeof(unsigned long long), st));
+        return SPPM_OK;
+    }
+    Grid g;
+    g.inv_cell = 1.0 / std::sqrt(r2max);
+    g.mask = nb - 1;
+    HIPCHK(hipMemsetAsync(c->d_cell_cnt, 0, sizeof(uint32_t) * nb, st));
+    hipLaunchKernelGGL(k_grid_count, dim3(2048), dim3(256), 0, st, c->rec_u, c->d_rec_count, g, c->d_cell_cnt, c->d_rec_bucket);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(nb / SCAN_BLOCK), dim3(SCAN_BLOCK), 0, st, c->d_cell_cnt, c->d_cell_start, c->d_block_sum);
+    hipLaunchKernelGGL(k_scan_tops, dim3(1), dim3(SCAN_BLOCK), 0, st, c->d_block_sum, (int)(nb / SCAN_BLOCK), c->d_total);
+    hipLaunchKernelGGL(k_scan_add, dim3(nb / SCAN_BLOCK), dim3(SCAN_BLOCK), 0, st, c->d_cell_start, c->d_block_sum, c->d_cursor, (size_t)nb, c->d_total);
+    hipLaunchKernelGGL(k_grid_scatter, dim3(2048), dim3(256), 0, st, c->rec_u, c->rec_s, c->d_rec_count, c->d_rec_bucket, c->d_cursor);
+    GatherParams gp;
+    gp.g = g; gp.gather_r2 = c->cfg.gather_radius2; gp.alpha = c->cfg.alpha; gp.rule = c->cfg.update_rule;
+    gp.first = c->pix_first; gp.count = c->pix_count;
+    gp.tap_key = c->d_tap_key; gp.tap_pix = c->d_tap_pix; gp.tap_n = c->d_tap_n; gp.tap_cap = c->tap_cap;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (c->timing) { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventRecord(e0, st)); }
+    hipLaunchKernelGGL(k_gather, dim3(nblk(c->pix_count, 256)), dim3(256), 0, st, c->hp, scene_of(c), c->rec_s, c->d_cell_start, gp, c->d_counters);
+    if (c->timing) { HIPCHK(hipEventRecord(e1, st)); c->ev.push_back({e0, e1}); }
+    HIPCHK(hipGetLastError());
+    // fold the record count into the counters and clear it for the next batch
+    unsigned long long cnt = 0;
+    HIPCHK(hipMemcpyAsync(&cnt, c->d_rec_count, sizeof cnt, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if ((int64_t)cnt > c->rec_u.cap) return fail(SPPM_ERR_OVERFLOW, "record buffer overflow: raise SPPM_RECORD_CAP or lower SPPM_BATCH_PHOTONS");
+    c->records_total += cnt;
+    c->gather_batches++;
+    HIPCHK(hipMemsetAsync(c->d_rec_count, 0, sizeof(unsigned long long), st));
+    return SPPM_OK;
+}
+
+extern "C" int sppm_photon_pass(sppm_ctx* c, int32_t pass, int64_t first, int64_t count)
+{
+    if (!c || pass < 0 || first < 0 || count < 0) return fail(SPPM_ERR_INVALID, "sppm_photon_pass: bad argument");
+    for (int64_t done = 0; done < count;) {
+        const int64_t n = std::min(c->batch_photons, count - done);
+        int rc = sppm_trace(c, pass, first + done, n);
+        if (rc) return rc;
+        rc = sppm_gather(c);
+        if (rc) return rc;
+        done += n;
+    }
+    return SPPM_OK;
+}
+
+extern "C" int sppm_end_pass(sppm_ctx* c)
+{
+    if (!c) return fail(SPPM_ERR_INVALID, "sppm_end_pass: null context");
+    if (c->cfg.update_rule != 1) return SPPM_OK;
+    hipLaunchKernelGGL(k_end_pass, dim3(nblk(c->pix_count, 256)), dim3(256), 0, c->stream, c->hp, c->pix_first, c->pix_count, c->cfg.alpha);
+    HIPCHK(hipGetLastError());
+    return SPPM_OK;
+}
+
+extern "C" int sppm_resolve(sppm_ctx* c, int32_t pass, int64_t photon_num, double* d_image)
+{
+    if (!c || !d_image || pass < 0 || photon_num < 1) return fail(SPPM_ERR_INVALID, "sppm_resolve: bad argument");
+    hipLaunchKernelGGL(k_resolve, dim3(nblk(c->P, 256)), dim3(256), 0, c->stream, c->hp, pass, photon_num, c->cfg.update_rule, d_image);
+    HIPCHK(hipGetLastError());
+    return SPPM_OK;
+}
+
+extern "C" int sppm_hdr_pixels(sppm_ctx* c, const double* d_rgb, int64_t n, uint8_t* d_rgbe)
+{
+    if (!c || n < 0 || (n > 0 && (!d_rgb || !d_rgbe))) return fail(SPPM_ERR_INVALID, "sppm_hdr_pixels: bad argument");
+    if (n == 0) return SPPM_OK;
+    hipLaunchKernelGGL(k_hdr_pixels, dim3(nblk(n, 256)), dim3(256), 0, c->stream, d_rgb, n, d_rgbe);
+    HIPCHK(hipGetLastError());
+    return SPPM_OK;
+}
+
+// save_hdr_file, src/hdr.h:48-89: header text, then per scanline 02 02 hi lo and the four channel
+// planes as literal chunks of at most 127 bytes.
+extern "C" int sppm_save_hdr_file(const char* filename, const double* h_image, int32_t width, int32_t height)
+{
+    if (!filename || !h_image || width < 1 || height < 1) return fail(SPPM_ERR_INVALID, "sppm_save_hdr_file: bad argument");
+    FILE* fp = fopen(filename, "wb");
+    if (!fp) return fail(SPPM_ERR_INVALID, std::string("sppm_save_hdr_file: cannot open ") + filename);  // the reference logs and returns (hdr.h:51-55)
+    fprintf(fp, "#?RADIANCE\n# Made with 100%% pure HDR Shop\nFORMAT=32-bit_rle_rgbe\nEXPOSURE=1.0000000000000\n\n-Y %d +X %d\n", height, width);
+    std::vector<uint8_t> line((size_t)width * 4), out;
+    for (int i = 0; i < height; i++) {
+        for (int j = 0; j < width; j++) {
+            const double* px = h_image + 3 * ((size_t)j + (size_t)i * width);
+            hdr_pixel(px[0], px[1], px[2], &line[4 * (size_t)j]);
+        }
+        out.clear();
+        out.push_back(0x02); out.push_back(0x02); out.push_back((uint8_t)((width >> 8) & 0xFF)); out.push_back((uint8_t)(width & 0xFF));
+        for (int ch = 0; ch < 4; ch++)
+            for (int cur = 0; cur < width;) {
+                const int mv = std::min(127, width - cur);
+                out.push_back((uint8_t)mv);
+                for (int j = cur; j < cur + mv; j++) out.push_back(line[4 * (size_t)j + ch]);
+                cur += mv;
+            }
+        fwrite(out.data(), 1, out.size(), fp);
+    }
+    fclose(fp);
+    return SPPM_OK;
+}
+
+// save_ppm_file, src/ppm.h:13-29 (the reference does not check fopen; this one reports it)
+extern "C" int sppm_save_ppm_file(const char* filename, const double* h_image, int32_t width, int32_t height)
+{
+    if (!filename || !h_image || width < 1 || height < 1) return fail(SPPM_ERR_INVALID, "sppm_save_ppm_file: bad argument");
+    FILE* f = fopen(filename, "wb");
+    if (!f) return fail(SPPM_ERR_INVALID, std::string("sppm_save_ppm_file: cannot open ") + filename);
+    fprintf(f, "P3\n%d %d\n%d\n", width, height, 255);
+    auto to_int = [](double x) {
+        if (x < 0.0) x = 0.0;
+        if (x > 1.0) x = 1.0;
+        return int(pow(x, 1 / 2.2) * 255 + 0.5);
+    };
+    for (int64_t i = 0; i < (int64_t)width * height; i++)
+        fprintf(f, "%d %d %d ", to_int(h_image[3 * i]), to_int(h_image[3 * i + 1]), to_int(h_image[3 * i + 2]));
+    fclose(f);
+    return SPPM_OK;
+}
+
+static int resolve_events(sppm_ctx* c)
+{
+    for (auto& e : c->ev) {
+        HIPCHK(hipEventSynchronize(e.second));
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, e.first, e.second));
+        c->gather_ns += (uint64_t)((double)ms * 1e6);
+        c->gather_launches++;
+        hipEventDestroy(e.first); hipEventDestroy(e.second);
+    }
+    c->ev.clear();
+    return 0;
+}
+
+extern "C" int sppm_check(sppm_ctx* c)
+{
+    if (!c) return fail(SPPM_ERR_INVALID, "sppm_check: null context");
+    int32_t err[4] = {0, 0, 0, 0};
+    HIPCHK(hipMemcpyAsync(err, c->d_err, sizeof err, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    int rc = resolve_events(c);
+    if (rc) return rc;
+    if (err[0]) return fail(SPPM_ERR_OVERFLOW, "record buffer overflow: raise SPPM_RECORD_CAP or lower SPPM_BATCH_PHOTONS");
+    if (err[1]) return fail(SPPM_ERR_OVERFLOW, "a photon path exceeded 32767 bounces");
+    if (err[2]) return fail(SPPM_ERR_OVERFLOW, "a query exceeded gather_max (the K cap is not implemented)");
+    return SPPM_OK;
+}
+
+extern "C" int sppm_download_hitpoints(sppm_ctx* c, int32_t* h_valid, int32_t* h_obj, double* h_hp_f, double* h_r2, int32_t* h_n,
+                                       double* h_flux, double* h_ld)
+{
+    if (!c) return fail(SPPM_ERR_INVALID, "sppm_download_hitpoints: null context");
+    const size_t P = (size_t)c->P;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    std::vector<int32_t> valid(P), obj(P);
+    HIPCHK(hipMemcpy(valid.data(), c->hp.valid, P * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(obj.data(), c->hp.obj, P * 4, hipMemcpyDeviceToHost));
+    if (h_valid) memcpy(h_valid, valid.data(), P * 4);
+    if (h_obj) for (size_t i = 0; i < P; i++) h_obj[i] = valid[i] ? obj[i] : -1;
+    if (h_hp_f) {
+        std::vector<double> pos(3 * P), nrm(3 * P), w(3 * P), dist(P);
+        HIPCHK(hipMemcpy(pos.data(), c->hp.pos, 3 * P * 8, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(nrm.data(), c->hp.nrm, 3 * P * 8, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(w.data(), c->hp.w, 3 * P * 8, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(dist.data(), c->hp.dist, P * 8, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < P; i++) {
+            double* f = h_hp_f + 10 * i;
+            f[0] = dist[i];
+            for (int k = 0; k < 3; k++) { f[1 + k] = pos[k * P + i]; f[4 + k] = nrm[k * P + i]; f[7 + k] = w[k * P + i]; }
+        }
+    }
+    if (h_r2) HIPCHK(hipMemcpy(h_r2, c->hp.r2, P * 8, hipMemcpyDeviceToHost));
+    if (h_n) {
+        if (c->cfg.update_rule == 0) HIPCHK(hipMemcpy(h_n, c->hp.n, P * 4, hipMemcpyDeviceToHost));
+        else {
+            std::vector<double> nd(P);
+            HIPCHK(hipMemcpy(nd.data(), c->hp.nd, P * 8, hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < P; i++) h_n[i] = (int32_t)nd[i];
+        }
+    }
+    auto soa3 = [&](const double* d, double* h) -> int {
+        std::vector<double> t(3 * P);
+        HIPCHK(hipMemcpy(t.data(), d, 3 * P * 8, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < P; i++) for (int k = 0; k < 3; k++) h[3 * i + k] = t[k * P + i];
+        return 0;
+    };
+    if (h_flux) { int rc = soa3(c->cfg.update_rule == 0 ? c->hp.flux : c->hp.tau, h_flux); if (rc) return rc; }
+    if (h_ld) { int rc = soa3(c->hp.ld, h_ld); if (rc) return rc; }
+    return SPPM_OK;
+}
+
+extern "C" int sppm_download_records(sppm_ctx* c, uint64_t* h_key, double* h_f, int64_t* n)
+{
+    if (!c || !n) return fail(SPPM_ERR_INVALID, "sppm_download_records: null argument");
+    int64_t cnt = 0;
+    int rc = sppm_records(c, nullptr, nullptr, &cnt, nullptr);
+    if (rc) return rc;
+    *n = cnt;
+    if (!h_key && !h_f) return SPPM_OK;
+    std::vector<uint64_t> key((size_t)cnt);
+    std::vector<double> f(9 * (size_t)cnt);
+    HIPCHK(hipMemcpy(key.data(), c->rec_u.key, (size_t)cnt * 8, hipMemcpyDeviceToHost));
+    for (int k = 0; k < 9; k++) HIPCHK(hipMemcpy(f.data() + (size_t)k * cnt, c->rec_u.f + (size_t)k * c->rec_u.cap, (size_t)cnt * 8, hipMemcpyDeviceToHost));
+    std::vector<int64_t> order((size_t)cnt);
+    for (int64_t i = 0; i < cnt; i++) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return key[a] < key[b]; });
+    for (int64_t i = 0; i < cnt; i++) {
+        if (h_key) h_key[i] = key[order[i]];
+        if (h_f) for (int k = 0; k < 9; k++) h_f[9 * i + k] = f[(size_t)k * cnt + order[i]];
+    }
+    return SPPM_OK;
+}
+
+extern "C" int sppm_accept_tap(sppm_ctx* c, int64_t cap)
+{
+    if (!c || cap < 0) return fail(SPPM_ERR_INVALID, "sppm_accept_tap: bad argument");
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->d_tap_key) { hipFree(c->d_tap_key); hipFree(c->d_tap_pix); hipFree(c->d_tap_n); c->d_tap_key = nullptr; c->d_tap_pix = nullptr; c->d_tap_n = nullptr; }
+    c->tap_cap = cap;
+    if (cap > 0) {
+        HIPCHK(hipMalloc((void**)&c->d_tap_key, (size_t)cap * 8));
+        HIPCHK(hipMalloc((void**)&c->d_tap_pix, (size_t)cap * 4));
+        HIPCHK(hipMalloc((void**)&c->d_tap_n, 8));
+        HIPCHK(hipMemset(c->d_tap_n, 0, 8));
+    }
+    return SPPM_OK;
+}
+
+extern "C" int sppm_download_accepted(sppm_ctx* c, uint64_t* h_key, int32_t* h_pix, int64_t* n)
+{
+    if (!c || !n) return fail(SPPM_ERR_INVALID, "sppm_download_accepted: null argument");
+    if (c->tap_cap <= 0) return fail(SPPM_ERR_STATE, "sppm_download_accepted: the tap is not enabled");
+    HIPCHK(hipStreamSynchronize(c->stream));
+    unsigned long long cnt = 0;
+    HIPCHK(hipMemcpy(&cnt, c->d_tap_n, 8, hipMemcpyDeviceToHost));
+    *n = (int64_t)cnt;
+    if ((int64_t)cnt > c->tap_cap) return fail(SPPM_ERR_OVERFLOW, "accept tap overflow");
+    if (!h_key || !h_pix) return SPPM_OK;
+    std::vector<uint64_t> key((size_t)cnt);
+    std::vector<int32_t> pix((size_t)cnt);
+    HIPCHK(hipMemcpy(key.data(), c->d_tap_key, (size_t)cnt * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(pix.data(), c->d_tap_pix, (size_t)cnt * 4, hipMemcpyDeviceToHost));
+    std::vector<int64_t> order((size_t)cnt);
+    for (int64_t i = 0; i < (int64_t)cnt; i++) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return key[a] != key[b] ? key[a] < key[b] : pix[a] < pix[b]; });
+    for (int64_t i = 0; i < (int64_t)cnt; i++) { h_key[i] = key[order[i]]; h_pix[i] = pix[order[i]]; }
+    return SPPM_OK;
+}
+
+extern "C" int sppm_counters(sppm_ctx* c, uint64_t h_out[8])
+{
+    if (!c || !h_out) return fail(SPPM_ERR_INVALID, "sppm_counters: null argument");
+    unsigned long long d[8];
+    HIPCHK(hipMemcpyAsync(d, c->d_counters, sizeof d, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    int rc = resolve_events(c);
+    if (rc) return rc;
+    h_out[0] = d[0]; h_out[1] = c->photons_traced; h_out[2] = c->records_total; h_out[3] = d[3]; h_out[4] = d[4];
+    h_out[5] = c->gather_batches; h_out[6] = c->gather_ns; h_out[7] = c->gather_launches;
+    return SPPM_OK;
+}
+
+extern "C" int sppm_set_timing(sppm_ctx* c, int32_t on)
+{
+    if (!c) return fail(SPPM_ERR_INVALID, "sppm_set_timing: null context");
+    c->timing = on ? 1 : 0;
+    return SPPM_OK;
+}

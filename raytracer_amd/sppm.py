@@ -1,0 +1,226 @@
+"""Host-side mirror of the reference's SPPM interface on top of the C ABI.
+
+`StochasticPpm(width, height, samples, supersamples).render(...)` takes the arguments of
+photonmap::sppm2::StochasticPpm<W,H>::render (/root/reference/src/sppm2.h:562-564) with the same
+meaning, writes the same per-pass `.ppm`/`.hdr` files (:687-694) and returns 0 like the reference.
+`SppmContext` exposes the individual stages and the parity taps.  PyTorch is used only to own device
+buffers and the HIP stream; all compute is in libsppm_hip.so.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi, scene
+
+
+def _sphere_array(table):
+    arr = (capi.SppmSphere * len(table))()
+    for s, (r, p, e, c, t) in zip(arr, table):
+        s.radius = r
+        s.position[:] = p
+        s.emission[:] = e
+        s.color[:] = c
+        s.reflection_type = t
+    return arr
+
+
+def make_config(width, height, *, samples=1, supersamples=1, camera_position=scene.CAMERA_POSITION, camera_dir=None,
+                camera_up=scene.CAMERA_UP, screen_height=scene.SCREEN_HEIGHT, screen_dist=scene.SCREEN_DIST, alpha=0.7,
+                initial_radius2=25.0, gather_radius2=25.0, gather_max=1 << 40, update_rule=0, double_nee=1,
+                seed_eye=1000, seed_photon=2000, photons_per_pass=0, pixel_first=0, pixel_count=0):
+    cfg = capi.SppmConfig()
+    cfg.width, cfg.height, cfg.samples, cfg.supersamples = width, height, samples, supersamples
+    cfg.camera_position[:] = camera_position
+    cfg.camera_dir[:] = camera_dir if camera_dir is not None else scene.camera_direction()
+    cfg.camera_up[:] = camera_up
+    cfg.screen_height, cfg.screen_dist = screen_height, screen_dist
+    cfg.alpha, cfg.initial_radius2 = alpha, initial_radius2
+    cfg.gather_radius2, cfg.gather_max = gather_radius2, gather_max
+    cfg.update_rule, cfg.double_nee = update_rule, double_nee
+    cfg.seed_eye, cfg.seed_photon = seed_eye, seed_photon
+    cfg.photons_per_pass = photons_per_pass
+    cfg.pixel_first, cfg.pixel_count = pixel_first, pixel_count
+    return cfg
+
+
+class SppmContext:
+    """One GPU's SPPM state: scene, camera, hitpoints, record buffers (sppm_create ... sppm_destroy)."""
+
+    def __init__(self, cfg, spheres=scene.CORNELL_SPHERES, device=None):
+        import torch
+
+        self.L = capi.lib()
+        if not torch.cuda.is_available() or self.L.sppm_device_count() < 1:
+            raise capi.SppmError("raytracer_amd needs a HIP device: there is no CPU path")
+        self.torch = torch
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        torch.cuda.set_device(self.device)
+        self.cfg = cfg
+        self.P = cfg.width * cfg.height
+        self._spheres = _sphere_array(spheres)
+        self.h = C.c_void_p()
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        capi.check(self.L.sppm_create(C.byref(cfg), self._spheres, len(self._spheres), C.c_void_p(stream), C.byref(self.h)))
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h:
+            self.L.sppm_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- stages -------------------------------------------------------------------------------
+    def camera_rays(self, sx=0, sy=0):
+        out = self.torch.empty((self.P, 6), dtype=self.torch.float64, device=self.device)
+        capi.check(self.L.sppm_camera_rays(self.h, sx, sy, out.data_ptr()))
+        return out
+
+    def intersect(self, rays):
+        t = self.torch
+        rays = rays.to(device=self.device, dtype=t.float64).contiguous()
+        n = rays.shape[0]
+        ids = t.empty((n,), dtype=t.int32, device=self.device)
+        hit = t.empty((n, 7), dtype=t.float64, device=self.device)
+        capi.check(self.L.sppm_intersect(self.h, rays.data_ptr(), n, ids.data_ptr(), hit.data_ptr()))
+        return ids, hit
+
+    def eye_pass(self, i):
+        capi.check(self.L.sppm_eye_pass(self.h, i))
+
+    def photon_pass(self, i, count, first=0):
+        capi.check(self.L.sppm_photon_pass(self.h, i, first, count))
+
+    def trace(self, i, first, count):
+        capi.check(self.L.sppm_trace(self.h, i, first, count))
+
+    def gather(self):
+        capi.check(self.L.sppm_gather(self.h))
+
+    def end_pass(self):
+        capi.check(self.L.sppm_end_pass(self.h))
+
+    def check(self):
+        capi.check(self.L.sppm_check(self.h))
+
+    def resolve(self, i, photon_num):
+        img = self.torch.empty((self.P, 3), dtype=self.torch.float64, device=self.device)
+        capi.check(self.L.sppm_resolve(self.h, i, photon_num, img.data_ptr()))
+        return img
+
+    def hdr_pixels(self, rgb):
+        t = self.torch
+        rgb = rgb.to(device=self.device, dtype=t.float64).contiguous()
+        out = t.empty((rgb.shape[0], 4), dtype=t.uint8, device=self.device)
+        capi.check(self.L.sppm_hdr_pixels(self.h, rgb.data_ptr(), rgb.shape[0], out.data_ptr()))
+        return out
+
+    # ---- records (multi-GPU exchange) ------------------------------------------------------------
+    def records(self):
+        """(device pointer of keys, device pointer of f[9][cap], count, cap)."""
+        k, f = C.c_void_p(), C.c_void_p()
+        n, cap = C.c_int64(), C.c_int64()
+        capi.check(self.L.sppm_records(self.h, C.byref(k), C.byref(f), C.byref(n), C.byref(cap)))
+        return k.value, f.value, n.value, cap.value
+
+    def set_record_count(self, n):
+        capi.check(self.L.sppm_set_record_count(self.h, n))
+
+    # ---- taps ------------------------------------------------------------------------------------
+    def hitpoints(self):
+        P = self.P
+        s = dict(valid=np.zeros(P, np.int32), obj=np.zeros(P, np.int32), hp_f=np.zeros((P, 10)), r2=np.zeros(P),
+                 n=np.zeros(P, np.int32), flux=np.zeros((P, 3)), ld=np.zeros((P, 3)))
+        capi.check(self.L.sppm_download_hitpoints(self.h, *[s[k].ctypes.data for k in ("valid", "obj", "hp_f", "r2", "n", "flux", "ld")]))
+        return s
+
+    def download_records(self):
+        n = C.c_int64()
+        capi.check(self.L.sppm_download_records(self.h, None, None, C.byref(n)))
+        key = np.zeros(n.value, np.uint64)
+        f = np.zeros((n.value, 9))
+        capi.check(self.L.sppm_download_records(self.h, key.ctypes.data, f.ctypes.data, C.byref(n)))
+        return key, f
+
+    def accept_tap(self, cap):
+        capi.check(self.L.sppm_accept_tap(self.h, cap))
+
+    def accepted(self):
+        n = C.c_int64()
+        capi.check(self.L.sppm_download_accepted(self.h, None, None, C.byref(n)))
+        key = np.zeros(n.value, np.uint64)
+        pix = np.zeros(n.value, np.int32)
+        capi.check(self.L.sppm_download_accepted(self.h, key.ctypes.data, pix.ctypes.data, C.byref(n)))
+        return key, pix
+
+    def counters(self):
+        out = np.zeros(8, np.uint64)
+        capi.check(self.L.sppm_counters(self.h, out.ctypes.data))
+        names = ("rays", "photons", "records", "candidates", "updates", "gather_batches", "gather_ns", "gather_launches")
+        return {k: int(v) for k, v in zip(names, out)}
+
+    def set_timing(self, on=True):
+        capi.check(self.L.sppm_set_timing(self.h, 1 if on else 0))
+
+
+def save_hdr_file(filename, image, width, height):
+    """photonmap::utility::save_hdr_file, src/hdr.h:48 (image: host array [H*W][3], row-major)."""
+    img = np.ascontiguousarray(image, dtype=np.float64)
+    capi.check(capi.lib().sppm_save_hdr_file(filename.encode(), img.ctypes.data, width, height))
+
+
+def save_ppm_file(filename, image, width, height):
+    """edupt::save_ppm_file, src/ppm.h:22."""
+    img = np.ascontiguousarray(image, dtype=np.float64)
+    capi.check(capi.lib().sppm_save_ppm_file(filename.encode(), img.ctypes.data, width, height))
+
+
+class StochasticPpm:
+    """Mirror of photonmap::sppm2::StochasticPpm<Width, Height> (src/sppm2.h:33-697).
+
+    Width/Height are constructor arguments here (template parameters in the reference).  The
+    tunables are the reference's public members (src/sppm2.h:38-44).
+    """
+
+    def __init__(self, width, height, samples, supersamples, spheres=scene.CORNELL_SPHERES):
+        self.width, self.height = width, height
+        self.samples, self.supersamples = samples, supersamples
+        self.alpha = 0.7
+        self.initial_radius_2 = 25.0
+        self.spheres = spheres
+        self.seed_eye, self.seed_photon = 1000, 2000
+        self.update_rule = 0
+        self.last_image = None
+
+    def render(self, filename, width, height, samples, supersamples, photon_num, gather_photon_radius,
+               gahter_max_photon_num, eye_pass_count=100, write_pass_files=True):
+        if (width, height) != (self.width, self.height):
+            raise ValueError("width/height must match the constructor's (template parameters in the reference)")
+        cfg = make_config(width, height, samples=samples, supersamples=supersamples, alpha=self.alpha,
+                          initial_radius2=self.initial_radius_2, gather_radius2=float(gather_photon_radius),
+                          gather_max=int(gahter_max_photon_num), update_rule=self.update_rule,
+                          seed_eye=self.seed_eye, seed_photon=self.seed_photon, photons_per_pass=photon_num)
+        ctx = SppmContext(cfg, self.spheres)
+        try:
+            image = None
+            for i in range(eye_pass_count):
+                ctx.eye_pass(i)
+                ctx.photon_pass(i, photon_num)
+                ctx.end_pass()
+                if write_pass_files or i == eye_pass_count - 1:
+                    image = ctx.resolve(i, photon_num).cpu().numpy()
+                    ctx.check()
+                if write_pass_files:
+                    save_ppm_file(f"{filename}_{i}.ppm", image, width, height)
+                    save_hdr_file(f"{filename}_{i}.hdr", image, width, height)
+            ctx.check()
+            if image is not None:
+                save_ppm_file(filename + ".ppm", image, width, height)
+                save_hdr_file(filename + ".hdr", image, width, height)
+            self.last_image = image
+        finally:
+            ctx.close()
+        return 0
