@@ -1,0 +1,145 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the SPPM hot path on MI355X (contract: see the task statement).
+
+A "step" is one SPPM pass at BASELINE config 2 geometry (Cornell box, 1920x1080, samples =
+supersamples = 1, alpha 0.7, initial r^2 = 25 = search r^2): eye pass over every pixel, 1M photons
+per GPU traced and applied to the hitpoints with the reference's per-photon update, image resolve.
+Nothing is uploaded inside the timed region (scene and state are resident in HBM).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+N > 1 (weak scaling, config 3): a pass has N x photons photons; every rank owns a slice of the
+hitpoints; photon paths are keyed by global photon index so the result does not depend on N.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def cpu_baseline(width, height, photons, seconds_target=12.0):
+    """The oracle (a faithful single-thread port of the reference's kd-tree SPPM) on this box's host
+    cores: eye pass 0 + kd build + a bounded number of photons of pass 0, same workload geometry."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol
+    from raytracer_amd.scene import CORNELL_SPHERES
+    par = ol.make_params(width, height, sampler=1, math=1, photons_per_pass=photons)
+    orc = ol.Oracle(par, ol.make_spheres(CORNELL_SPHERES))
+    t0 = time.perf_counter()
+    orc.eye_pass(0)
+    t_eye = time.perf_counter() - t0
+    n, done, t_ph = 2000, 0, 0.0
+    while t_ph < seconds_target and done < photons:
+        n = min(n, photons - done)
+        t0 = time.perf_counter()
+        orc.photon_pass(0, n, first=done)
+        t_ph += time.perf_counter() - t0
+        done += n
+        n *= 2
+    upd = orc.counters()["updates"]
+    orc.close()
+    return {"value": done / t_ph, "unit": "photons/s", "cores": 1, "kind": "port",
+            "sample": f"{width}x{height} pass 0: eye pass + kd-tree build {t_eye:.1f} s (not in value), then the first "
+                      f"{done} photons in {t_ph:.1f} s, {upd} hitpoint updates ({upd / t_ph:.3g} updates/s)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--photons", type=int, default=1_000_000, help="photons per pass per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch N > 1 through torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    from raytracer_amd import sppm
+    from raytracer_amd.parallel import ShardedSppm
+
+    W, H, M = args.width, args.height, args.photons
+    job = ShardedSppm(W, H, photons_per_rank=M, rank=rank, world=world)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    step = 0
+    for _ in range(args.warmup):
+        job.step(step)
+        step += 1
+    job.ctx.check()
+    job.ctx.set_timing(True)
+    c0 = job.ctx.counters()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        job.step(step)
+        step += 1
+    barrier()
+    dt = time.perf_counter() - t0
+    job.ctx.check()
+    c1 = job.ctx.counters()
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    # per-rank counter deltas summed over ranks (each rank applies updates to its own hitpoints)
+    d = torch.tensor([c1[k] - c0[k] for k in ("rays", "records", "candidates", "updates")], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(d, op=dist.ReduceOp.SUM)
+    dt = float(tmax.item())
+    rays, records, cand, upd = [float(x) for x in d.tolist()]
+
+    if rank == 0:
+        photons_total = float(M) * world * args.steps
+        g_ns = c1["gather_ns"] - c0["gather_ns"]
+        g_launch = max(1, c1["gather_launches"] - c0["gather_launches"])
+        cand0, upd0 = c1["candidates"] - c0["candidates"], c1["updates"] - c0["updates"]
+        # 28 B per candidate hitpoint/record pair examined, +32 B per accepted update
+        alg_bytes = 28.0 * cand0 + 32.0 * upd0
+        achieved = alg_bytes / max(g_ns, 1) if g_ns else 0.0  # bytes/ns == GB/s
+        out = {
+            "metric": "photons traced/sec + hitpoint updates/sec (whole node), SPPM Cornell 1080p",
+            "value": photons_total / dt, "unit": "photons/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"Cornell-box SPPM {W}x{H}, {M} photons/pass/GPU, passes {args.warmup}..{args.warmup + args.steps - 1} "
+                                   f"of a fresh render, alpha 0.7, initial r^2 25, search r^2 25, per-photon update (sppm2.h), "
+                                   f"XorShift streams", "photons_per_pass": M * world, "width": W, "height": H,
+                       "parallelism": job.describe()},
+            "hitpoint_updates_per_s": upd / dt, "rays_per_s": rays / dt, "records_per_photon": records / max(1.0, float(M) * args.steps * (world if job.replicated_trace else 1)),
+            "updates_per_photon": upd / photons_total,
+            "roofline": {"bound": "hbm", "kernel": "k_gather", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                         "frac": achieved / 8000.0, "traffic": None,
+                         "launches": int(g_launch), "avg_launch_ms": g_ns / 1e6 / g_launch,
+                         "alg_bytes_per_launch": alg_bytes / g_launch,
+                         "note": "rank 0; algorithmic bytes = 28 B x candidate pairs examined + 32 B x accepted updates (SURVEY 8d)"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(W, H, M)
+        print(json.dumps(out), flush=True)
+    job.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,81 @@
+"""The oracle (oracle/sppm_oracle.c, sampler = MT19937, math = libm) against golden vectors made by
+the compiled, unmodified reference (tests/golden/make_golden.py).  Everything is compared bit for
+bit: this is what pins the oracle.  CPU only."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from raytracer_amd.scene import CORNELL_SPHERES
+
+
+def _bits(a, b, what):
+    a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+    assert a.shape == b.shape, what
+    ok = (a.view(np.uint64) == b.view(np.uint64)) if a.dtype.kind == "f" else (a == b)
+    assert ok.all(), f"{what}: {(~ok).sum()} of {ok.size} differ"
+
+
+def test_stateless_pieces(golden):
+    g = golden("64x48")
+    sph = ol.make_spheres(CORNELL_SPHERES)
+    p = ol.make_params(64, 48, sampler=0, math=0)
+    _bits(ol.camera_rays(p), g["cam_rays"], "PinholeCamera::get_ray")
+    for tag in ("cam", "rnd"):
+        ids, f = ol.intersect(sph, g[f"{tag}_rays"])
+        _bits(ids, g[f"{tag}_hit_id"], f"{tag} first-hit ids")
+        m = ids >= 0
+        _bits(f[m], g[f"{tag}_hit_f"][m], f"{tag} hit records")
+    _bits(ol.mt_samples(4242, 4096), g["mt_samples_seed4242"], "ValueSampler<double> sequence")
+    for i, s in enumerate((0, 1, 12345)):
+        u, f01 = ol.xorshift(s, 16)
+        _bits(u, g["xorshift_u32"][i], "XorShift::next")
+        _bits(f01, g["xorshift_01"][i], "XorShift::next01")
+    _bits(ol.hdr_pixels(g["encode_in"]), g["encode_rgbe"], "get_hdr_pixel")
+    _bits(ol.to_int(g["encode_in"]).reshape(-1, 3), g["encode_toint"], "to_int")
+
+
+@pytest.mark.parametrize("tag", ["64x48", "64x48_r5", "320x240"])
+def test_sppm_passes(golden, tag):
+    g = golden(tag)
+    w, h, photons, passes, traced, k, se, sp = [int(x) for x in g["meta"]]
+    st = int(g["stride"][0])
+    p = ol.make_params(w, h, sampler=0, math=0, gather_radius2=float(g["gather_r2"][0]), gather_max=k, seed_eye=se,
+                       seed_photon=sp, photons_per_pass=photons)
+    o = ol.Oracle(p, ol.make_spheres(CORNELL_SPHERES))
+    img = None
+    for i in range(passes):
+        o.eye_pass(i)
+        s = o.state()
+        _bits(s["valid"] > 0, g[f"hp_valid_pass{i}"] > 0, f"pass {i} which pixels own a hitpoint")
+        _bits(s["obj"].astype(np.int8), g[f"hp_obj_pass{i}"], f"pass {i} hitpoint object ids")
+        _bits(s["hp_f"][::st], g[f"hp_f_pass{i}"][:, :10], f"pass {i} hitpoint records")
+        _bits(s["ld"][::st], g[f"ld_pass{i}"], f"pass {i} direct term (incl. the double first-sight sample)")
+        assert o.counters()["eye_draws"] * 2 == int(g[f"eye_words_pass{i}"][0]), "eye stream position"
+        t = o.photon_pass(i, photons, tap=True, acc_cap=40_000_000)
+        s = o.state()
+        v = s["valid"] > 0
+        _bits(s["n"][v], g[f"state_n_pass{i}"][v], f"pass {i} photon counts")
+        _bits(s["r2"][::st], g[f"state_f_pass{i}"][:, 0], f"pass {i} radii")
+        _bits(s["flux"][::st], g[f"state_f_pass{i}"][:, 1:], f"pass {i} flux")
+        nw = len(g[f"ph_words_pass{i}"])
+        _bits(t["draws"][:nw] * 2, g[f"ph_words_pass{i}"], f"pass {i} engine words per photon")
+        # accepted hitpoint sets of the first nw photons
+        ph = t["rec_photon"][t["acc_rec"]]
+        sel = ph < nw
+        order = np.lexsort((t["acc_pix"][sel], ph[sel]))
+        ph_s, px_s = ph[sel][order], t["acc_pix"][sel][order]
+        pairs, cnt = np.unique(np.stack([ph_s, px_s], 1), axis=0, return_counts=True)
+        off = g[f"ph_acc_off_pass{i}"]
+        ref_ph = np.repeat(np.arange(nw), np.diff(off))
+        _bits(pairs[:, 0], ref_ph, f"pass {i} accepted sets (photon)")
+        _bits(pairs[:, 1], g[f"ph_acc_pix_pass{i}"], f"pass {i} accepted sets (image index)")
+        _bits(cnt.astype(np.int8), g[f"ph_acc_cnt_pass{i}"], f"pass {i} accepted multiplicity")
+        img = o.resolve(i, photons)
+        _bits(img[::st], g[f"image_pass{i}"], f"pass {i} image")
+        assert img.sum() == g[f"sums_pass{i}"][3]
+    assert ol.hdr_file(img, w, h) == g["final_hdr"].tobytes(), "save_hdr_file bytes"
+    if "final_ppm" in g:
+        assert ol.ppm_file(img, w, h) == g["final_ppm"].tobytes(), "save_ppm_file bytes"
+    else:
+        import hashlib
+        assert hashlib.sha256(ol.ppm_file(img, w, h)).digest() == g["final_ppm_sha256"].tobytes()
