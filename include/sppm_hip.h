@@ -69,9 +69,9 @@ typedef struct sppm_config {
     int64_t photons_per_pass; /* photons of one pass over ALL ranks; keys the per-photon XorShift
                                  streams (key = pass*photons_per_pass + i), so a photon's path does
                                  not depend on which GPU traces it */
-    int32_t pixel_first, pixel_count; /* this rank's slice of image indices for the gather/update
-                                         (0,0 = all).  Eye pass and tracing always cover what the
-                                         calls ask for; see sppm_gather. */
+    int32_t tile_first, tile_stride; /* this rank gathers for the 8x8 pixel tiles tile_first + k*tile_stride
+                                        (tiles numbered row-major over the image-index grid); 0,0 = all tiles.
+                                        The eye pass and tracing always cover what the calls ask for. */
     int32_t check_gather_max;
     int32_t reserved_[3];
 } sppm_config;
@@ -148,11 +148,12 @@ int sppm_download_records(sppm_ctx* ctx, uint64_t* h_key, double* h_f, int64_t* 
 int sppm_accept_tap(sppm_ctx* ctx, int64_t cap);
 int sppm_download_accepted(sppm_ctx* ctx, uint64_t* h_key, int32_t* h_pix, int64_t* n);
 
-/* counters since creation: [0] rays cast, [1] photons traced, [2] photon-hit records, [3] candidate
- * (record, hitpoint) pairs examined, [4] accepted hitpoint updates, [5] gather batches,
- * [6] nanoseconds of device time in the gather kernel as measured by HIP events when timing is on,
- * [7] gather kernel launches timed. */
-int sppm_counters(sppm_ctx* ctx, uint64_t h_out[8]);
+/* counters since creation: [0] rays cast, [1] photons traced, [2] photon-hit records, [3] records
+ * enumerated from grid cells by the gather, [4] accepted hitpoint updates, [5] gather batches,
+ * [6] nanoseconds of device time in the gather kernel (HIP events on the context's stream, when
+ * timing is on), [7] gather kernel launches timed, [8] in-region candidates staged, [9] staging rounds,
+ * [10] live tile launches, [11] reserved. */
+int sppm_counters(sppm_ctx* ctx, uint64_t h_out[12]);
 int sppm_set_timing(sppm_ctx* ctx, int32_t on);
 
 #ifdef __cplusplus

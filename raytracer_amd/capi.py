@@ -31,7 +31,7 @@ class SppmConfig(C.Structure):
                 ("update_rule", C.c_int32), ("double_nee", C.c_int32),
                 ("seed_eye", C.c_uint32), ("seed_photon", C.c_uint32),
                 ("photons_per_pass", C.c_int64),
-                ("pixel_first", C.c_int32), ("pixel_count", C.c_int32),
+                ("tile_first", C.c_int32), ("tile_stride", C.c_int32),
                 ("check_gather_max", C.c_int32), ("reserved_", C.c_int32 * 3)]
 
 

@@ -1,0 +1,324 @@
+// sppm_gather_tiles.hpp -- the tile gather: one wavefront replays, for the 64 hitpoints of an 8x8
+// pixel tile, every photon-hit record near the tile in key (= photon, bounce) order.
+//
+// Included by sppm_kernels.hip.  Semantics are exactly those of k_gather (the simple per-hitpoint
+// kernel kept as a cross-check): the search filter of src/kdtree.h:123-127, the acceptance test and
+// the per-photon update of src/sppm2.h:391-421 (rule 0) or the deposit of
+// src/stochastic_ppm.h:439-456 (rule 1), applied per hitpoint in ascending key order.
+//
+// How the order is obtained without sorting records by time globally:
+//   * records of a batch are counting-sorted by (slab, cell): slab = photon index / B (time),
+//     cell = dense grid cell of size c (space).  Inside a bucket the order is arbitrary.
+//   * a tile walks the slabs in order.  For a slab it looks up the cells that overlap its region
+//     (tile bounding box grown by the largest radius of the tile), pulls the candidate records that
+//     fall inside the region into an LDS staging list of at most 64, ranks them by key (counting
+//     rank, one candidate per lane) and applies them in rank order: the record is broadcast from
+//     its lane with v_readlane and each lane tests it against its own hitpoint.
+//   * more than 64 candidates in a slab: the slab's key range is halved until it fits (keys are
+//     unique, so this terminates); the next attempt takes the rest of the slab.
+// Everything that steers control flow (cell ranges, counts, ranks, source lanes) is wave-uniform.
+#pragma once
+
+struct TileGrid {
+    double ox, oy, oz, inv_c;
+    int nx, ny, nz, ncells;
+    int S;          // slabs in this batch
+    int64_t B;      // photons per slab
+    int64_t first;  // first photon index of the batch
+};
+
+struct TileParams {
+    TileGrid g;
+    double gather_r2, alpha;
+    int rule;
+    int W, H, tiles_x, n_tiles, tile_first, tile_stride, n_owned;
+    uint64_t* tap_key; int32_t* tap_pix; unsigned long long* tap_n; int64_t tap_cap;
+};
+
+__device__ __forceinline__ double rl_d(double v, int lane)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double first_d(double v)
+{
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+    const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_max_d(double v)
+{
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off));
+    return first_d(v);
+}
+__device__ __forceinline__ double wave_min_d(double v)
+{
+    for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off));
+    return first_d(v);
+}
+// grid coordinate of x, clamped to [0, n-1]; monotone in x, so an interval maps to an index range
+__device__ __forceinline__ int grid_coord(double x, double o, double inv_c, int n)
+{
+    const double f = floor((x - o) * inv_c);
+    return f < 0.0 ? 0 : (f > (double)(n - 1) ? n - 1 : (int)f);
+}
+
+__device__ __forceinline__ int tile_of_pixel(int p, int W, int tiles_x) { return ((p / W) >> 3) * tiles_x + ((p % W) >> 3); }
+
+// (slab, cell) bucket of every record of the batch
+__global__ void k_bin_count(RecArrays rec, const unsigned long long* __restrict__ rec_count, TileGrid g, uint32_t* __restrict__ cell_cnt,
+                            uint32_t* __restrict__ rec_bucket)
+{
+    const int64_t n = min((int64_t)*rec_count, rec.cap);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ix = grid_coord(rec.f[i], g.ox, g.inv_c, g.nx);
+        const int iy = grid_coord(rec.f[rec.cap + i], g.oy, g.inv_c, g.ny);
+        const int iz = grid_coord(rec.f[2 * rec.cap + i], g.oz, g.inv_c, g.nz);
+        int64_t slab = ((int64_t)(rec.key[i] >> 16) - g.first) / g.B;
+        slab = slab < 0 ? 0 : (slab >= g.S ? g.S - 1 : slab);  // records from outside the batch's photon range stay ordered by key anyway
+        const uint32_t b = (uint32_t)slab * (uint32_t)g.ncells + (uint32_t)((iz * g.ny + iy) * g.nx + ix);
+        rec_bucket[i] = b;
+        atomicAdd(&cell_cnt[b], 1u);
+    }
+}
+
+// Global statistics of the owned tiles, to size the grid: bounding box of all hitpoints (ordered-int
+// encoded doubles), a histogram of log2(tile region extent) and the number of live tiles.
+struct TileStats { unsigned long long bb[6]; unsigned int hist[64]; unsigned int live_tiles; unsigned int pad; };
+__device__ __forceinline__ unsigned long long ord_d(double v)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__global__ void __launch_bounds__(256) k_tile_stats(HpArrays hp, TileParams tp, TileStats* __restrict__ st)
+{
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int k = blockIdx.x * 4 + wv;
+    if (k >= tp.n_owned) return;
+    const int tile = tp.tile_first + k * tp.tile_stride;
+    const int col = (tile % tp.tiles_x) * 8 + (lane & 7), row = (tile / tp.tiles_x) * 8 + (lane >> 3);
+    const int P = hp.P, p = row * tp.W + col;
+    bool live = (col < tp.W) && (row < tp.H);
+    if (live) live = hp.valid[p] != 0;
+    if (__ballot(live) == 0) return;
+    const double BIG = 1e300;
+    const double x = live ? hp.pos[p] : 0.0, y = live ? hp.pos[P + p] : 0.0, z = live ? hp.pos[2 * P + p] : 0.0;
+    const double r = live ? sqrt(fmin(hp.r2[p], tp.gather_r2)) : 0.0;
+    const double x0 = wave_min_d(live ? x : BIG), x1 = wave_max_d(live ? x : -BIG);
+    const double y0 = wave_min_d(live ? y : BIG), y1 = wave_max_d(live ? y : -BIG);
+    const double z0 = wave_min_d(live ? z : BIG), z1 = wave_max_d(live ? z : -BIG);
+    const double rm = wave_max_d(r);
+    if (lane == 0) {
+        const double ext = fmax(x1 - x0, fmax(y1 - y0, z1 - z0)) + 2.0 * rm;
+        int e;
+        frexp(ext, &e);  // ext in [2^(e-1), 2^e)
+        e = e + 32;
+        e = e < 0 ? 0 : (e > 63 ? 63 : e);
+        atomicAdd(&st->hist[e], 1u);
+        atomicAdd(&st->live_tiles, 1u);
+        atomicMin(&st->bb[0], ord_d(x0 - rm)); atomicMin(&st->bb[1], ord_d(y0 - rm)); atomicMin(&st->bb[2], ord_d(z0 - rm));
+        atomicMax(&st->bb[3], ord_d(x1 + rm)); atomicMax(&st->bb[4], ord_d(y1 + rm)); atomicMax(&st->bb[5], ord_d(z1 + rm));
+    }
+}
+
+__global__ void __launch_bounds__(256) k_gather_tiles(HpArrays hp, DevScene sc, RecArrays rec, const uint32_t* __restrict__ cell_start,
+                                                      TileParams tp, unsigned long long* __restrict__ counters)
+{
+    __shared__ unsigned long long s_key[4][64];
+    __shared__ uint32_t s_rec[4][64];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int k = blockIdx.x * 4 + wv;
+    if (k >= tp.n_owned) return;
+    const int tile = tp.tile_first + k * tp.tile_stride;
+    const int col = (tile % tp.tiles_x) * 8 + (lane & 7), row = (tile / tp.tiles_x) * 8 + (lane >> 3);
+    const int P = hp.P, p = row * tp.W + col;
+    bool live = (col < tp.W) && (row < tp.H);
+    if (live) live = hp.valid[p] != 0;
+    if (__ballot(live) == 0) return;
+
+    d3 hpos = mk(0, 0, 0), hn = mk(0, 0, 0), hw = mk(0, 0, 0), hcol = mk(0, 0, 0), acc = mk(0, 0, 0);
+    double r2 = 0.0;
+    int n = 0, madd = 0;
+    if (live) {
+        hpos = mk(hp.pos[p], hp.pos[P + p], hp.pos[2 * P + p]);
+        hn = mk(hp.nrm[p], hp.nrm[P + p], hp.nrm[2 * P + p]);
+        hw = mk(hp.w[p], hp.w[P + p], hp.w[2 * P + p]);
+        hcol = ld3(sc.sp[hp.obj[p]].color);
+        r2 = hp.r2[p];
+        if (tp.rule == 0) { n = hp.n[p]; acc = mk(hp.flux[p], hp.flux[P + p], hp.flux[2 * P + p]); }
+        else { madd = hp.madd[p]; acc = mk(hp.phi[p], hp.phi[P + p], hp.phi[2 * P + p]); }
+    }
+    const double BIG = 1e300;
+    const double bx0 = wave_min_d(live ? hpos.x : BIG), bx1 = wave_max_d(live ? hpos.x : -BIG);
+    const double by0 = wave_min_d(live ? hpos.y : BIG), by1 = wave_max_d(live ? hpos.y : -BIG);
+    const double bz0 = wave_min_d(live ? hpos.z : BIG), bz1 = wave_max_d(live ? hpos.z : -BIG);
+    const double thr = tp.gather_r2 * 0.01;
+    const double band_rel = 1e-9 + 8e-15 / thr;
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const int64_t cap = rec.cap;
+    unsigned int c_cand = 0, c_sel = 0, c_acc = 0, c_round = 0;  // wave-uniform tallies except c_acc (per lane)
+
+    for (int s = 0; s < tp.g.S; s++) {
+        // region of this slab: bounding box grown by the largest radius any lane can still accept at
+        const double rr = live ? sqrt(fmin(r2, tp.gather_r2)) * (1.0 + 1e-9) + 1e-9 : 0.0;
+        const double rmax = wave_max_d(rr);
+        const double lx = bx0 - rmax, hx = bx1 + rmax, ly = by0 - rmax, hy = by1 + rmax, lz = bz0 - rmax, hz = bz1 + rmax;
+        const int cx0 = __builtin_amdgcn_readfirstlane(grid_coord(lx, tp.g.ox, tp.g.inv_c, tp.g.nx));
+        const int cx1 = __builtin_amdgcn_readfirstlane(grid_coord(hx, tp.g.ox, tp.g.inv_c, tp.g.nx));
+        const int cy0 = __builtin_amdgcn_readfirstlane(grid_coord(ly, tp.g.oy, tp.g.inv_c, tp.g.ny));
+        const int cy1 = __builtin_amdgcn_readfirstlane(grid_coord(hy, tp.g.oy, tp.g.inv_c, tp.g.ny));
+        const int cz0 = __builtin_amdgcn_readfirstlane(grid_coord(lz, tp.g.oz, tp.g.inv_c, tp.g.nz));
+        const int cz1 = __builtin_amdgcn_readfirstlane(grid_coord(hz, tp.g.oz, tp.g.inv_c, tp.g.nz));
+        const int kx = cx1 - cx0 + 1, ky = cy1 - cy0 + 1, kz = cz1 - cz0 + 1;
+        const int Ktot = kx * ky * kz;
+        const uint32_t slab_base = (uint32_t)s * (uint32_t)tp.g.ncells;
+        const unsigned long long kend = (s == tp.g.S - 1) ? ~0ull : ((unsigned long long)(tp.g.first + (int64_t)(s + 1) * tp.g.B) << 16);
+        unsigned long long klo = (s == 0) ? 0ull : ((unsigned long long)(tp.g.first + (int64_t)s * tp.g.B) << 16);
+        unsigned long long khi = kend;
+        while (klo < kend) {
+            // ---- collect the candidates with key in [klo, khi) inside the region into LDS (at most 64)
+            int sel_n = 0;
+            bool overflow = false;
+            for (int qbase = 0; qbase < Ktot && !overflow; qbase += 64) {
+                const int q = qbase + lane;
+                uint32_t cs = 0, cn = 0;
+                if (q < Ktot) {
+                    const int ix = cx0 + q % kx, iy = cy0 + (q / kx) % ky, iz = cz0 + q / (kx * ky);
+                    const uint32_t b = slab_base + (uint32_t)((iz * tp.g.ny + iy) * tp.g.nx + ix);
+                    cs = cell_start[b];
+                    cn = cell_start[b + 1] - cs;
+                }
+                uint32_t incl = cn;  // inclusive scan over the wave
+                for (int off = 1; off < 64; off <<= 1) { const uint32_t y = __shfl_up(incl, off); if (lane >= off) incl += y; }
+                const uint32_t pre = incl - cn;
+                const int tot = __builtin_amdgcn_readlane((int)incl, 63);
+                for (int cbase = 0; cbase < tot && !overflow; cbase += 64) {
+                    const int i = cbase + lane;
+                    const bool has = i < tot;
+                    // the cell lane j that owns candidate i: the largest j with pre_j <= i
+                    int j = 0;
+                    for (int step = 32; step >= 1; step >>= 1) {
+                        const int cand = j + step;
+                        const uint32_t pv = __shfl(pre, cand & 63);
+                        if (cand < 64 && pv <= (uint32_t)i) j = cand;
+                    }
+                    const uint32_t r = __shfl(cs, j) + ((uint32_t)i - __shfl(pre, j));
+                    bool in = false;
+                    unsigned long long key = 0;
+                    if (has) {
+                        key = rec.key[r];
+                        in = key >= klo && key < khi;
+                        if (in) {
+                            const double qx = rec.f[r], qy = rec.f[cap + r], qz = rec.f[2 * cap + r];
+                            in = qx >= lx && qx <= hx && qy >= ly && qy <= hy && qz >= lz && qz <= hz;
+                        }
+                    }
+                    c_cand += (unsigned int)__popcll(__ballot(has));
+                    const unsigned long long m = __ballot(in);
+                    const int cnt = __popcll(m);
+                    if (sel_n + cnt > 64) { overflow = true; break; }
+                    if (in) {
+                        const int slot = sel_n + __popcll(m & lt_mask);
+                        s_key[wv][slot] = key;
+                        s_rec[wv][slot] = r;
+                    }
+                    sel_n += cnt;
+                }
+            }
+            if (overflow) { khi = klo + (khi - klo) / 2; continue; }
+            if (sel_n > 0) {
+                __builtin_amdgcn_wave_barrier();
+                c_sel += (unsigned int)sel_n;
+                c_round++;
+                // ---- one candidate per lane: load it, rank it by key
+                const bool own = lane < sel_n;
+                unsigned long long mykey = ~0ull;
+                d3 q = mk(0, 0, 0), gn = mk(0, 0, 0), pf = mk(0, 0, 0);
+                if (own) {
+                    mykey = s_key[wv][lane];
+                    const uint32_t r = s_rec[wv][lane];
+                    q = mk(rec.f[r], rec.f[cap + r], rec.f[2 * cap + r]);
+                    gn = mk(rec.f[3 * cap + r], rec.f[4 * cap + r], rec.f[5 * cap + r]);
+                    pf = mk(rec.f[6 * cap + r], rec.f[7 * cap + r], rec.f[8 * cap + r]);
+                }
+                int rank = 0;
+                for (int jj = 0; jj < sel_n; jj++) rank += (s_key[wv][jj] < mykey) ? 1 : 0;
+                __builtin_amdgcn_wave_barrier();
+                // ---- apply in key order
+                for (int t = 0; t < sel_n; t++) {
+                    const unsigned long long ms = __ballot(own && rank == t);
+                    const int src = __ffsll((long long)ms) - 1;
+                    const d3 qq = mk(rl_d(q.x, src), rl_d(q.y, src), rl_d(q.z, src));
+                    const d3 dir = hpos - qq;
+                    const double d2 = len2(dir);
+                    bool ok = live && (d2 < tp.gather_r2) && (d2 <= r2);
+                    if (__ballot(ok) == 0) continue;
+                    const d3 g0 = mk(rl_d(gn.x, src), rl_d(gn.y, src), rl_d(gn.z, src));
+                    ok = ok && (dot(hn, g0) > 1e-3);
+                    if (__ballot(ok) == 0) continue;
+                    const int klow = __builtin_amdgcn_readlane((int)(unsigned int)mykey, src);
+                    const d3 on = (klow & 1) ? g0 * -1.0 : g0;
+                    {   // flatness filter |dot(on, dir/sqrt(d2))| <= thr, decided without the square root
+                        // and the three divisions unless the squared form is within rounding of the bound
+                        const double s1 = dot(on, dir);
+                        const double lhs = s1 * s1, rhs = thr * thr * d2;
+                        const double band = rhs * band_rel;
+                        const bool sure_pass = lhs < rhs - band, sure_fail = lhs > rhs + band;
+                        bool flat = sure_pass;
+                        const bool unsure = ok && !sure_pass && !sure_fail;
+                        if (__ballot(unsure) != 0) {
+                            if (unsure) {
+                                const double dt = dot(on, dir / sqrt(d2));  // NaN at d2 == 0: rejected as in the reference
+                                flat = fabs(dt) <= thr;
+                            }
+                        }
+                        ok = ok && flat;
+                    }
+                    if (__ballot(ok) == 0) continue;
+                    const d3 ff = mk(rl_d(pf.x, src), rl_d(pf.y, src), rl_d(pf.z, src));
+                    if (ok) {
+                        if (tp.rule == 0) {  // src/sppm2.h:397-419
+                            double g;
+                            if (n != 0) g = (n * tp.alpha + tp.alpha) / (n * tp.alpha + 1.0);
+                            else g = 1;
+                            r2 = r2 * g;
+                            n++;
+                            acc = (acc + had(hw, had(hcol, ff)) / SPPM_PI) * g;
+                        } else {             // src/stochastic_ppm.h:449-454
+                            const d3 f = hcol / SPPM_PI;
+                            acc = acc + had(ff, f);
+                            madd++;
+                        }
+                        c_acc++;
+                        if (tp.tap_cap > 0) {
+                            const unsigned long long kfull = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(mykey >> 32), src) << 32) |
+                                                             (unsigned int)klow;
+                            const unsigned long long slot = atomicAdd(tp.tap_n, 1ull);
+                            if ((int64_t)slot < tp.tap_cap) { tp.tap_key[slot] = kfull; tp.tap_pix[slot] = p; }
+                        }
+                    }
+                }
+            }
+            klo = khi;
+            khi = kend;
+        }
+    }
+    if (live) {
+        if (tp.rule == 0) {
+            hp.r2[p] = r2; hp.n[p] = n;
+            hp.flux[p] = acc.x; hp.flux[P + p] = acc.y; hp.flux[2 * P + p] = acc.z;
+        } else {
+            hp.madd[p] = madd;
+            hp.phi[p] = acc.x; hp.phi[P + p] = acc.y; hp.phi[2 * P + p] = acc.z;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) c_acc += __shfl_down(c_acc, off);
+    if (lane == 0) {
+        if (c_cand) atomicAdd(&counters[3], (unsigned long long)c_cand);
+        if (c_acc) atomicAdd(&counters[4], (unsigned long long)c_acc);
+        if (c_sel) atomicAdd(&counters[5], (unsigned long long)c_sel);
+        if (c_round) atomicAdd(&counters[6], (unsigned long long)c_round);
+        atomicAdd(&counters[7], 1ull);  // live tiles
+    }
+}

@@ -346,12 +346,17 @@ __global__ void k_grid_scatter(RecArrays src, RecArrays dst, const unsigned long
 }
 
 // max over valid hitpoints of min(r2, gather_r2), as an ordered-int atomic max on the bit pattern
-__global__ void k_r2max(HpArrays hp, int first, int count, double gather_r2, unsigned long long* __restrict__ out)
+struct Own { int W, tiles_x, tile_first, tile_stride; };
+__device__ __forceinline__ bool owned(const Own& o, int p)
+{
+    const int t = ((p / o.W) >> 3) * o.tiles_x + ((p % o.W) >> 3) - o.tile_first;
+    return t >= 0 && (t % o.tile_stride) == 0;
+}
+__global__ void k_r2max(HpArrays hp, Own own, double gather_r2, unsigned long long* __restrict__ out)
 {
     double m = 0.0;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
-        const int p = first + i;
-        if (hp.valid[p]) { const double r = fmin(hp.r2[p], gather_r2); m = fmax(m, r); }
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < hp.P; p += gridDim.x * blockDim.x) {
+        if (hp.valid[p] && owned(own, p)) { const double r = fmin(hp.r2[p], gather_r2); m = fmax(m, r); }
     }
     for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_down(m, off));
     if ((threadIdx.x & 63) == 0 && m > 0.0) atomicMax(out, (unsigned long long)__double_as_longlong(m));
@@ -359,7 +364,7 @@ __global__ void k_r2max(HpArrays hp, int first, int count, double gather_r2, uns
 
 // ---- gather: each hitpoint replays the records near it in key order ------------------------------------
 struct GatherParams {
-    Grid g; double gather_r2, alpha; int rule; int first, count;
+    Grid g; double gather_r2, alpha; int rule; Own own;
     uint64_t* tap_key; int32_t* tap_pix; unsigned long long* tap_n; int64_t tap_cap;
 };
 
@@ -386,10 +391,10 @@ __global__ void __launch_bounds__(256) k_gather(HpArrays hp, DevScene sc, RecArr
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t n_cand = 0, n_acc = 0;
-    if (t < gp.count) {
-        const int p = gp.first + t;
+    if (t < hp.P) {
+        const int p = t;
         const int P = hp.P;
-        if (hp.valid[p]) {
+        if (hp.valid[p] && owned(gp.own, p)) {
             const d3 hpos = mk(hp.pos[p], hp.pos[P + p], hp.pos[2 * P + p]);
             const d3 hn = mk(hp.nrm[p], hp.nrm[P + p], hp.nrm[2 * P + p]);
             const d3 hw = mk(hp.w[p], hp.w[P + p], hp.w[2 * P + p]);
@@ -480,12 +485,12 @@ __global__ void __launch_bounds__(256) k_gather(HpArrays hp, DevScene sc, RecArr
 }
 
 // end-of-pass update of rule 1, src/stochastic_ppm.h:721-741
-__global__ void k_end_pass(HpArrays hp, int first, int count, double alpha)
+__global__ void k_end_pass(HpArrays hp, Own own, double alpha)
 {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= count) return;
-    const int p = first + t, P = hp.P;
-    if (!hp.valid[p]) return;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int P = hp.P;
+    if (p >= P) return;
+    if (!hp.valid[p] || !owned(own, p)) return;
     const int madd = hp.madd[p];
     if (madd > 0) {
         const double N = hp.nd[p], r2 = hp.r2[p];
@@ -538,6 +543,8 @@ __global__ void k_hdr_pixels(const double* __restrict__ rgb, int64_t n, uint8_t*
     out[4 * i] = px[0]; out[4 * i + 1] = px[1]; out[4 * i + 2] = px[2]; out[4 * i + 3] = px[3];
 }
 
+#include "sppm_gather_tiles.hpp"
+
 // ================================ host side / C ABI =================================================
 
 static thread_local std::string g_err;
@@ -553,7 +560,14 @@ struct sppm_ctx {
     int device;
     hipStream_t stream;
     int P;
-    int pix_first, pix_count;
+    int tiles_x, tiles_y, n_tiles, tile_first, tile_stride, n_owned;
+    int gather_mode;          // 1 = tile gather (default), 0 = simple per-hitpoint gather (cross-check)
+    int64_t table_cap;        // entries of the (slab, cell) table
+    double cell_factor;
+    int64_t slab_B;           // photons per slab, adapted from the previous batch
+    int64_t rec_first, rec_end;  // photon index range of the records in the buffer
+    uint64_t photons_applied; // photons gathered so far (sizes the next batch)
+    TileStats* d_stats;
     sppm_sphere* d_spheres; int ns;
     Camera cam;
     double flux_scale;
@@ -561,7 +575,7 @@ struct sppm_ctx {
     HpArrays hp;
     RecArrays rec_u, rec_s;  // unsorted (traced / received), sorted by bucket
     unsigned long long* d_rec_count;
-    unsigned long long* d_counters;  // 8
+    unsigned long long* d_counters;  // 8: [0] rays [3] candidates [4] updates [5] selected [6] rounds [7] live tile launches
     unsigned long long* d_r2max;
     int32_t* d_err;                  // 4
     uint32_t *d_cell_cnt, *d_cell_start, *d_cursor, *d_block_sum, *d_total, *d_rec_bucket;
@@ -628,9 +642,20 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
     c->cfg = *cfg;
     c->stream = (hipStream_t)stream;
     c->P = cfg->width * cfg->height;
-    c->pix_first = cfg->pixel_count > 0 ? cfg->pixel_first : 0;
-    c->pix_count = cfg->pixel_count > 0 ? cfg->pixel_count : c->P;
-    if (c->pix_first < 0 || c->pix_first + c->pix_count > c->P) { delete c; return fail(SPPM_ERR_INVALID, "sppm_create: pixel slice out of range"); }
+    c->tiles_x = (cfg->width + 7) / 8; c->tiles_y = (cfg->height + 7) / 8; c->n_tiles = c->tiles_x * c->tiles_y;
+    c->tile_stride = cfg->tile_stride > 0 ? cfg->tile_stride : 1;
+    c->tile_first = cfg->tile_stride > 0 ? cfg->tile_first : 0;
+    if (c->tile_first < 0 || c->tile_first >= c->tile_stride) { delete c; return fail(SPPM_ERR_INVALID, "sppm_create: need 0 <= tile_first < tile_stride"); }
+    c->n_owned = c->tile_first < c->n_tiles ? (c->n_tiles - c->tile_first + c->tile_stride - 1) / c->tile_stride : 0;
+    c->gather_mode = (int)env_i64("SPPM_GATHER_TILES", 1);
+    c->table_cap = env_i64("SPPM_TABLE_CAP", 1ll << 24);
+    if (c->table_cap < 4096) c->table_cap = 4096;
+    if (c->table_cap > (1ll << 24)) c->table_cap = 1ll << 24;
+    c->cell_factor = 0.5;
+    { const char* e = getenv("SPPM_CELL_FACTOR"); if (e && *e) c->cell_factor = atof(e); }
+    c->slab_B = env_i64("SPPM_SLAB_PHOTONS", 1024);
+    c->rec_first = c->rec_end = 0;
+    c->photons_applied = 0;
     c->ns = n_spheres;
     c->tap_cap = 0; c->d_tap_key = nullptr; c->d_tap_pix = nullptr; c->d_tap_n = nullptr;
     c->timing = 0; c->gather_ns = c->gather_launches = c->gather_batches = 0; c->photons_traced = c->records_total = 0;
@@ -665,9 +690,9 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
         TRY(dev_alloc(c, &c->hp.phi, 3 * P)); TRY(dev_alloc(c, &c->hp.tau, 3 * P)); TRY(dev_alloc(c, &c->hp.nd, P)); TRY(dev_alloc(c, &c->hp.madd, P));
     } else { c->hp.phi = c->hp.tau = c->hp.nd = nullptr; c->hp.madd = nullptr; }
     // record buffers: one batch of photons, ~2.6 records per photon on the Cornell scene; 8x head room
-    c->batch_photons = env_i64("SPPM_BATCH_PHOTONS", 1 << 18);
+    c->batch_photons = env_i64("SPPM_BATCH_PHOTONS", c->gather_mode ? (1 << 20) : (1 << 18));
     if (c->batch_photons < 1024) c->batch_photons = 1024;
-    const int64_t cap = env_i64("SPPM_RECORD_CAP", c->batch_photons * 8);
+    const int64_t cap = env_i64("SPPM_RECORD_CAP", c->batch_photons * (c->gather_mode ? 4 : 8));
     c->rec_u.cap = c->rec_s.cap = cap;
     TRY(dev_alloc(c, &c->rec_u.key, (size_t)cap, false)); TRY(dev_alloc(c, &c->rec_u.f, 9 * (size_t)cap, false));
     TRY(dev_alloc(c, &c->rec_s.key, (size_t)cap, false)); TRY(dev_alloc(c, &c->rec_s.f, 9 * (size_t)cap, false));
@@ -675,9 +700,11 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
     uint32_t nb = 1024;
     while ((int64_t)nb < cap / 2 && nb < (1u << 24)) nb <<= 1;
     c->n_buckets = nb;
+    if (c->gather_mode) nb = (uint32_t)((c->table_cap + SCAN_BLOCK) / SCAN_BLOCK * SCAN_BLOCK);
     TRY(dev_alloc(c, &c->d_cell_cnt, (size_t)nb)); TRY(dev_alloc(c, &c->d_cell_start, (size_t)nb + 1)); TRY(dev_alloc(c, &c->d_cursor, (size_t)nb));
     TRY(dev_alloc(c, &c->d_block_sum, (size_t)nb / SCAN_BLOCK + 1)); TRY(dev_alloc(c, &c->d_total, 1));
     TRY(dev_alloc(c, &c->d_rec_count, 1)); TRY(dev_alloc(c, &c->d_counters, 8)); TRY(dev_alloc(c, &c->d_r2max, 1)); TRY(dev_alloc(c, &c->d_err, 4));
+    TRY(dev_alloc(c, &c->d_stats, 1));
 #undef TRY
     if (hipStreamSynchronize(c->stream) != hipSuccess) { sppm_destroy(c); return fail(SPPM_ERR_HIP, "sppm_create: stream sync failed"); }
     *out = c;
@@ -737,6 +764,8 @@ extern "C" int sppm_trace(sppm_ctx* c, int32_t pass, int64_t first, int64_t coun
     hipLaunchKernelGGL(k_photon_trace, dim3(nblk(count, 256)), dim3(256), 0, c->stream, scene_of(c), tp, c->rec_u, c->d_rec_count, c->d_counters, c->d_err);
     HIPCHK(hipGetLastError());
     c->photons_traced += (uint64_t)count;
+    if (c->rec_end == c->rec_first) { c->rec_first = first; c->rec_end = first + count; }
+    else { c->rec_first = std::min(c->rec_first, first); c->rec_end = std::max(c->rec_end, first + count); }
     return SPPM_OK;
 }
 
@@ -765,58 +794,168 @@ extern "C" int sppm_set_record_count(sppm_ctx* c, int64_t n)
     return SPPM_OK;
 }
 
-// grid build + ordered gather over whatever is in the unsorted record buffer; clears the buffer
-extern "C" int sppm_gather(sppm_ctx* c)
+static inline Own own_of(const sppm_ctx* c) { Own o; o.W = c->cfg.width; o.tiles_x = c->tiles_x; o.tile_first = c->tile_first; o.tile_stride = c->tile_stride; return o; }
+
+static int run_scan(sppm_ctx* c, uint32_t n_padded)
 {
-    if (!c) return fail(SPPM_ERR_INVALID, "sppm_gather: null context");
     hipStream_t st = c->stream;
-    const uint32_t nb = c->n_buckets;
-    // cell size = sqrt of the largest squared bound any of this rank's hitpoints uses
-    HIPCHK(hipMemsetAsync(c->d_r2max, 0, sizeof(unsigned long long), st));
-    hipLaunchKernelGGL(k_r2max, dim3(std::min(nblk(c->pix_count, 256), 2048)), dim3(256), 0, st, c->hp, c->pix_first, c->pix_count, c->cfg.gather_radius2, c->d_r2max);
-    unsigned long long bits = 0;
-    HIPCHK(hipMemcpyAsync(&bits, c->d_r2max, sizeof bits, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    double r2max;
-    memcpy(&r2max, &bits, 8);
-    if (!(r2max > 0.0)) {  // no valid hitpoint on this rank: nothing can be accepted
-        HIPCHK(hipMemsetAsync(c->d_rec_count, 0, sizeof(unsigned long long), st));
-        return SPPM_OK;
-    }
-    Grid g;
-    g.inv_cell = 1.0 / std::sqrt(r2max);
-    g.mask = nb - 1;
-    HIPCHK(hipMemsetAsync(c->d_cell_cnt, 0, sizeof(uint32_t) * nb, st));
-    hipLaunchKernelGGL(k_grid_count, dim3(2048), dim3(256), 0, st, c->rec_u, c->d_rec_count, g, c->d_cell_cnt, c->d_rec_bucket);
-    hipLaunchKernelGGL(k_scan_blocks, dim3(nb / SCAN_BLOCK), dim3(SCAN_BLOCK), 0, st, c->d_cell_cnt, c->d_cell_start, c->d_block_sum);
-    hipLaunchKernelGGL(k_scan_tops, dim3(1), dim3(SCAN_BLOCK), 0, st, c->d_block_sum, (int)(nb / SCAN_BLOCK), c->d_total);
-    hipLaunchKernelGGL(k_scan_add, dim3(nb / SCAN_BLOCK), dim3(SCAN_BLOCK), 0, st, c->d_cell_start, c->d_block_sum, c->d_cursor, (size_t)nb, c->d_total);
-    hipLaunchKernelGGL(k_grid_scatter, dim3(2048), dim3(256), 0, st, c->rec_u, c->rec_s, c->d_rec_count, c->d_rec_bucket, c->d_cursor);
-    GatherParams gp;
-    gp.g = g; gp.gather_r2 = c->cfg.gather_radius2; gp.alpha = c->cfg.alpha; gp.rule = c->cfg.update_rule;
-    gp.first = c->pix_first; gp.count = c->pix_count;
-    gp.tap_key = c->d_tap_key; gp.tap_pix = c->d_tap_pix; gp.tap_n = c->d_tap_n; gp.tap_cap = c->tap_cap;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (c->timing) { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventRecord(e0, st)); }
-    hipLaunchKernelGGL(k_gather, dim3(nblk(c->pix_count, 256)), dim3(256), 0, st, c->hp, scene_of(c), c->rec_s, c->d_cell_start, gp, c->d_counters);
-    if (c->timing) { HIPCHK(hipEventRecord(e1, st)); c->ev.push_back({e0, e1}); }
+    hipLaunchKernelGGL(k_scan_blocks, dim3(n_padded / SCAN_BLOCK), dim3(SCAN_BLOCK), 0, st, c->d_cell_cnt, c->d_cell_start, c->d_block_sum);
+    hipLaunchKernelGGL(k_scan_tops, dim3(1), dim3(SCAN_BLOCK), 0, st, c->d_block_sum, (int)(n_padded / SCAN_BLOCK), c->d_total);
+    hipLaunchKernelGGL(k_scan_add, dim3(n_padded / SCAN_BLOCK), dim3(SCAN_BLOCK), 0, st, c->d_cell_start, c->d_block_sum, c->d_cursor, (size_t)n_padded, c->d_total);
     HIPCHK(hipGetLastError());
-    // fold the record count into the counters and clear it for the next batch
+    return 0;
+}
+
+static int finish_batch(sppm_ctx* c)
+{
+    hipStream_t st = c->stream;
     unsigned long long cnt = 0;
     HIPCHK(hipMemcpyAsync(&cnt, c->d_rec_count, sizeof cnt, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     if ((int64_t)cnt > c->rec_u.cap) return fail(SPPM_ERR_OVERFLOW, "record buffer overflow: raise SPPM_RECORD_CAP or lower SPPM_BATCH_PHOTONS");
     c->records_total += cnt;
     c->gather_batches++;
+    c->photons_applied += (uint64_t)(c->rec_end - c->rec_first);
+    c->rec_first = c->rec_end = 0;
     HIPCHK(hipMemsetAsync(c->d_rec_count, 0, sizeof(unsigned long long), st));
     return SPPM_OK;
+}
+
+// Simple gather (cross-check path, SPPM_GATHER_TILES=0): hash grid over the records, one thread per
+// hitpoint selecting its next keys by rescanning its neighbourhood.
+static int gather_simple(sppm_ctx* c)
+{
+    hipStream_t st = c->stream;
+    const uint32_t nb = c->n_buckets;
+    HIPCHK(hipMemsetAsync(c->d_r2max, 0, sizeof(unsigned long long), st));
+    hipLaunchKernelGGL(k_r2max, dim3(std::min(nblk(c->P, 256), 2048)), dim3(256), 0, st, c->hp, own_of(c), c->cfg.gather_radius2, c->d_r2max);
+    unsigned long long bits = 0;
+    HIPCHK(hipMemcpyAsync(&bits, c->d_r2max, sizeof bits, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    double r2max;
+    memcpy(&r2max, &bits, 8);
+    if (!(r2max > 0.0)) return finish_batch(c);  // no valid hitpoint on this rank: nothing can be accepted
+    Grid g;
+    g.inv_cell = 1.0 / std::sqrt(r2max);
+    g.mask = nb - 1;
+    HIPCHK(hipMemsetAsync(c->d_cell_cnt, 0, sizeof(uint32_t) * nb, st));
+    hipLaunchKernelGGL(k_grid_count, dim3(2048), dim3(256), 0, st, c->rec_u, c->d_rec_count, g, c->d_cell_cnt, c->d_rec_bucket);
+    int rc = run_scan(c, nb);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_grid_scatter, dim3(2048), dim3(256), 0, st, c->rec_u, c->rec_s, c->d_rec_count, c->d_rec_bucket, c->d_cursor);
+    GatherParams gp;
+    gp.g = g; gp.gather_r2 = c->cfg.gather_radius2; gp.alpha = c->cfg.alpha; gp.rule = c->cfg.update_rule;
+    gp.own = own_of(c);
+    gp.tap_key = c->d_tap_key; gp.tap_pix = c->d_tap_pix; gp.tap_n = c->d_tap_n; gp.tap_cap = c->tap_cap;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (c->timing) { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventRecord(e0, st)); }
+    hipLaunchKernelGGL(k_gather, dim3(nblk(c->P, 256)), dim3(256), 0, st, c->hp, scene_of(c), c->rec_s, c->d_cell_start, gp, c->d_counters);
+    if (c->timing) { HIPCHK(hipEventRecord(e1, st)); c->ev.push_back({e0, e1}); }
+    HIPCHK(hipGetLastError());
+    return finish_batch(c);
+}
+
+static double undo_ord(unsigned long long o)
+{
+    const unsigned long long b = (o >> 63) ? (o & 0x7fffffffffffffffull) : ~o;
+    double d;
+    memcpy(&d, &b, 8);
+    return d;
+}
+
+// Tile gather: size the (slab, cell) grid from the tiles' current regions, counting-sort the records
+// into it, then one wavefront per 8x8 tile replays its records in key order (k_gather_tiles).
+static int gather_tiles(sppm_ctx* c)
+{
+    hipStream_t st = c->stream;
+    if (c->n_owned == 0 || c->rec_end == c->rec_first) return finish_batch(c);
+    TileParams tp;
+    memset(&tp, 0, sizeof tp);
+    tp.gather_r2 = c->cfg.gather_radius2; tp.alpha = c->cfg.alpha; tp.rule = c->cfg.update_rule;
+    tp.W = c->cfg.width; tp.H = c->cfg.height; tp.tiles_x = c->tiles_x; tp.n_tiles = c->n_tiles;
+    tp.tile_first = c->tile_first; tp.tile_stride = c->tile_stride; tp.n_owned = c->n_owned;
+    tp.tap_key = c->d_tap_key; tp.tap_pix = c->d_tap_pix; tp.tap_n = c->d_tap_n; tp.tap_cap = c->tap_cap;
+    // --- statistics of the tiles' regions
+    TileStats hs;
+    memset(&hs, 0, sizeof hs);
+    hs.bb[0] = hs.bb[1] = hs.bb[2] = ~0ull;
+    HIPCHK(hipMemcpyAsync(c->d_stats, &hs, sizeof hs, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_tile_stats, dim3(nblk(c->n_owned, 4)), dim3(256), 0, st, c->hp, tp, c->d_stats);
+    unsigned long long cnt0[8];
+    HIPCHK(hipMemcpyAsync(&hs, c->d_stats, sizeof hs, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(cnt0, c->d_counters, sizeof cnt0, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (hs.live_tiles == 0) return finish_batch(c);
+    // median of the tiles' region extents (upper edge of the log2 bin)
+    int med = 0;
+    { unsigned int acc = 0; for (int e = 0; e < 64; e++) { acc += hs.hist[e]; if (2 * acc >= hs.live_tiles) { med = e; break; } } }
+    double cell = std::ldexp(1.0, med - 32) * c->cell_factor;
+    double lo[3], hi[3];
+    for (int k = 0; k < 3; k++) { lo[k] = undo_ord(hs.bb[k]); hi[k] = undo_ord(hs.bb[3 + k]); }
+    int64_t dims[3], ncells;
+    for (;;) {
+        ncells = 1;
+        for (int k = 0; k < 3; k++) { dims[k] = std::max<int64_t>(1, (int64_t)std::ceil((hi[k] - lo[k]) / cell)); ncells *= dims[k]; if (ncells > (1ll << 40)) break; }
+        if (ncells <= c->table_cap / 4) break;
+        cell *= 1.25;
+    }
+    const int64_t range = c->rec_end - c->rec_first;
+    int64_t B = std::max<int64_t>(64, std::min<int64_t>(c->slab_B, range));
+    int64_t S = (range + B - 1) / B;
+    if (S * ncells > c->table_cap) { S = std::max<int64_t>(1, c->table_cap / ncells); B = (range + S - 1) / S; S = (range + B - 1) / B; }
+    TileGrid g;
+    g.ox = lo[0]; g.oy = lo[1]; g.oz = lo[2]; g.inv_c = 1.0 / cell;
+    g.nx = (int)dims[0]; g.ny = (int)dims[1]; g.nz = (int)dims[2]; g.ncells = (int)ncells;
+    g.S = (int)S; g.B = B; g.first = c->rec_first;
+    tp.g = g;
+    const uint32_t n_table = (uint32_t)(S * ncells);
+    const uint32_t n_padded = (n_table + SCAN_BLOCK - 1) / SCAN_BLOCK * SCAN_BLOCK;
+    HIPCHK(hipMemsetAsync(c->d_cell_cnt, 0, sizeof(uint32_t) * n_padded, st));
+    hipLaunchKernelGGL(k_bin_count, dim3(2048), dim3(256), 0, st, c->rec_u, c->d_rec_count, g, c->d_cell_cnt, c->d_rec_bucket);
+    int rc = run_scan(c, n_padded);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_grid_scatter, dim3(2048), dim3(256), 0, st, c->rec_u, c->rec_s, c->d_rec_count, c->d_rec_bucket, c->d_cursor);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (c->timing) { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventRecord(e0, st)); }
+    hipLaunchKernelGGL(k_gather_tiles, dim3(nblk(c->n_owned, 4)), dim3(256), 0, st, c->hp, scene_of(c), c->rec_s, c->d_cell_start, tp, c->d_counters);
+    if (c->timing) { HIPCHK(hipEventRecord(e1, st)); c->ev.push_back({e0, e1}); }
+    HIPCHK(hipGetLastError());
+    unsigned long long cnt1[8];
+    HIPCHK(hipMemcpyAsync(cnt1, c->d_counters, sizeof cnt1, hipMemcpyDeviceToHost, st));
+    rc = finish_batch(c);  // synchronises
+    if (rc) return rc;
+    // adapt the slab length: aim at ~20 in-region candidates per (tile, slab), far from the 64 of one round
+    const double tiles_run = (double)(cnt1[7] - cnt0[7]);
+    if (tiles_run > 0 && !getenv("SPPM_SLAB_PHOTONS")) {
+        const double avg = (double)(cnt1[5] - cnt0[5]) / (tiles_run * (double)S);
+        double f = avg > 0 ? 20.0 / avg : 4.0;
+        f = std::min(4.0, std::max(0.25, f));
+        c->slab_B = std::max<int64_t>(64, (int64_t)((double)B * f));
+    }
+    if (getenv("SPPM_DEBUG"))
+        fprintf(stderr, "[sppm] batch %lld photons: cell %.3f grid %dx%dx%d S=%d B=%lld rounds/tile-slab %.2f sel/tile-slab %.2f cand/sel %.2f next B %lld\n",
+                (long long)range, cell, g.nx, g.ny, g.nz, g.S, (long long)B, (double)(cnt1[6] - cnt0[6]) / std::max(1.0, tiles_run * S),
+                (double)(cnt1[5] - cnt0[5]) / std::max(1.0, tiles_run * S), (double)(cnt1[3] - cnt0[3]) / std::max(1.0, (double)(cnt1[5] - cnt0[5])),
+                (long long)c->slab_B);
+    return SPPM_OK;
+}
+
+// grid build + ordered gather over whatever is in the unsorted record buffer; clears the buffer
+extern "C" int sppm_gather(sppm_ctx* c)
+{
+    if (!c) return fail(SPPM_ERR_INVALID, "sppm_gather: null context");
+    return c->gather_mode ? gather_tiles(c) : gather_simple(c);
 }
 
 extern "C" int sppm_photon_pass(sppm_ctx* c, int32_t pass, int64_t first, int64_t count)
 {
     if (!c || pass < 0 || first < 0 || count < 0) return fail(SPPM_ERR_INVALID, "sppm_photon_pass: bad argument");
     for (int64_t done = 0; done < count;) {
-        const int64_t n = std::min(c->batch_photons, count - done);
+        // Batches grow with the photons already applied: the radii shrink like N^-0.43, so a batch
+        // about half as long as the history changes them little while it runs.
+        int64_t n = c->batch_photons;
+        if (c->gather_mode) n = std::min<int64_t>(n, std::max<int64_t>(32768, (int64_t)(c->photons_applied / 2)));
+        n = std::min(n, count - done);
         int rc = sppm_trace(c, pass, first + done, n);
         if (rc) return rc;
         rc = sppm_gather(c);
@@ -830,7 +969,7 @@ extern "C" int sppm_end_pass(sppm_ctx* c)
 {
     if (!c) return fail(SPPM_ERR_INVALID, "sppm_end_pass: null context");
     if (c->cfg.update_rule != 1) return SPPM_OK;
-    hipLaunchKernelGGL(k_end_pass, dim3(nblk(c->pix_count, 256)), dim3(256), 0, c->stream, c->hp, c->pix_first, c->pix_count, c->cfg.alpha);
+    hipLaunchKernelGGL(k_end_pass, dim3(nblk(c->P, 256)), dim3(256), 0, c->stream, c->hp, own_of(c), c->cfg.alpha);
     HIPCHK(hipGetLastError());
     return SPPM_OK;
 }
@@ -1028,7 +1167,7 @@ extern "C" int sppm_download_accepted(sppm_ctx* c, uint64_t* h_key, int32_t* h_p
     return SPPM_OK;
 }
 
-extern "C" int sppm_counters(sppm_ctx* c, uint64_t h_out[8])
+extern "C" int sppm_counters(sppm_ctx* c, uint64_t h_out[12])
 {
     if (!c || !h_out) return fail(SPPM_ERR_INVALID, "sppm_counters: null argument");
     unsigned long long d[8];
@@ -1038,6 +1177,7 @@ extern "C" int sppm_counters(sppm_ctx* c, uint64_t h_out[8])
     if (rc) return rc;
     h_out[0] = d[0]; h_out[1] = c->photons_traced; h_out[2] = c->records_total; h_out[3] = d[3]; h_out[4] = d[4];
     h_out[5] = c->gather_batches; h_out[6] = c->gather_ns; h_out[7] = c->gather_launches;
+    h_out[8] = d[5]; h_out[9] = d[6]; h_out[10] = d[7]; h_out[11] = 0;
     return SPPM_OK;
 }
 

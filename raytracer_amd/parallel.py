@@ -3,8 +3,8 @@
 What shards and what does not (DESIGN.md "Multi-GPU"):
   * The reference's per-photon update (src/sppm2.h:391-421) is sequential per HITPOINT, not per
     photon: a hitpoint's state depends on the time-ordered photons near it, and on nothing else.
-    So the hitpoints are partitioned across ranks (contiguous slices of image indices) and every
-    rank replays, for its own hitpoints, the photon-hit records of the WHOLE pass in key order.
+    So the hitpoints are partitioned across ranks (8x8 pixel tiles dealt round-robin, which also
+    balances bright and dark image regions) and every rank replays, for its own hitpoints, the photon-hit records of the WHOLE pass in key order.
     The result is bit-identical for every world size.
   * Photon tracing is independent per photon (streams keyed by global photon index).  Two ways to
     give every rank all records of a pass:
@@ -20,11 +20,17 @@ import numpy as np
 from . import scene, sppm
 
 
-def pixel_slice(P, rank, world):
-    """Contiguous slice [first, first+count) of image indices owned by `rank`; sizes differ by <= 1."""
-    base, rem = divmod(P, world)
-    first = rank * base + min(rank, rem)
-    return first, base + (1 if rank < rem else 0)
+def tile_grid(width, height):
+    """8x8 pixel tiles over the image-index grid: (tiles_x, tiles_y)."""
+    return (width + 7) // 8, (height + 7) // 8
+
+
+def owner_of_pixels(width, height, world):
+    """int32 array [H*W]: the rank that owns each image index (tile t belongs to rank t % world)."""
+    tx, _ = tile_grid(width, height)
+    idx = np.arange(width * height)
+    tile = (idx // width // 8) * tx + (idx % width) // 8
+    return (tile % world).astype(np.int32)
 
 
 class ShardedSppm:
@@ -38,16 +44,14 @@ class ShardedSppm:
         self.M = photons_per_rank * world
         self.exchange = exchange if world > 1 else "replicate"
         self.replicated_trace = self.exchange == "replicate"
-        first, count = pixel_slice(self.P, rank, world)
-        self.first, self.count = first, count
-        cfg = sppm.make_config(width, height, photons_per_pass=self.M, pixel_first=first, pixel_count=count, **cfg_kw)
+        cfg = sppm.make_config(width, height, photons_per_pass=self.M, tile_first=rank, tile_stride=world, **cfg_kw)
         self.ctx = sppm.SppmContext(cfg, spheres)
         self.image = None
 
     def describe(self):
         if self.world == 1:
             return "1 GPU"
-        return f"{self.world} ranks: hitpoints sliced by image index, photon records by {self.exchange}"
+        return f"{self.world} ranks: 8x8 hitpoint tiles dealt round-robin, photon records by {self.exchange}"
 
     def step(self, i, resolve=True):
         """One SPPM pass: eye pass, photon pass of self.M photons, progressive update, image resolve."""
@@ -66,21 +70,22 @@ class ShardedSppm:
         raise NotImplementedError("exchange='allgather' needs sppm_pack_records/sppm_append_records (next step)")
 
     def gather_image(self):
-        """Full image on every rank: each rank contributes its slice (one all-gather)."""
+        """Full image on every rank: every rank's resolve is valid on the tiles it owns; one
+        all-gather, then a select by owner."""
         import torch
         import torch.distributed as dist
         if self.world == 1:
             return self.image
-        base = -(-self.P // self.world)
-        mine = torch.zeros((base, 3), dtype=torch.float64, device=self.image.device)
-        mine[: self.count] = self.image[self.first: self.first + self.count]
-        out = torch.empty((self.world * base, 3), dtype=torch.float64, device=self.image.device)
-        dist.all_gather_into_tensor(out, mine)
-        full = torch.empty((self.P, 3), dtype=torch.float64, device=self.image.device)
-        for r in range(self.world):
-            f, c = pixel_slice(self.P, r, self.world)
-            full[f: f + c] = out[r * base: r * base + c]
-        return full
+        out = torch.empty((self.world,) + tuple(self.image.shape), dtype=torch.float64, device=self.image.device)
+        dist.all_gather_into_tensor(out, self.image.contiguous())
+        return select_by_owner(out, owner_of_pixels(self.W, self.H, self.world))
 
     def close(self):
         self.ctx.close()
+
+
+def select_by_owner(stacked, owner):
+    """stacked[world][P][3] -> [P][3], taking pixel p from rank owner[p] (works on CPU and GPU tensors)."""
+    import torch
+    idx = torch.as_tensor(owner, dtype=torch.int64, device=stacked.device)
+    return stacked[idx, torch.arange(stacked.shape[1], device=stacked.device)]

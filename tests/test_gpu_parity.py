@@ -109,12 +109,18 @@ def test_passes_match_oracle_bit_for_bit(r2, passes):
     ctx.close()
 
 
-def test_batching_does_not_change_results(monkeypatch):
-    """The ordered gather is exact, so the batch size must not matter: 4 small batches == 1 batch."""
-    W, H, M = 64, 48, 16384
+def test_gather_kernels_and_slab_lengths_agree(monkeypatch):
+    """The ordered gather is exact, so how records are bucketed must not matter: the simple
+    per-hitpoint kernel, and the tile kernel at three slab lengths (64 forces many slabs, 1<<20 forces
+    the >64-candidates key-range halving), all give the same bits."""
+    W, H, M = 64, 48, 40000
     outs = []
-    for batch in (4096, 1 << 18):
-        monkeypatch.setenv("SPPM_BATCH_PHOTONS", str(batch))
+    for env in (dict(SPPM_GATHER_TILES="0"), dict(SPPM_SLAB_PHOTONS="64"), dict(SPPM_SLAB_PHOTONS="3000"),
+                dict(SPPM_SLAB_PHOTONS="1048576"), dict(SPPM_CELL_FACTOR="0.13"), dict(SPPM_CELL_FACTOR="3.0")):
+        for k in ("SPPM_GATHER_TILES", "SPPM_SLAB_PHOTONS", "SPPM_CELL_FACTOR"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
         ctx = sppm.SppmContext(sppm.make_config(W, H, photons_per_pass=M))
         for i in range(2):
             ctx.eye_pass(i)
@@ -122,8 +128,30 @@ def test_batching_does_not_change_results(monkeypatch):
         ctx.check()
         outs.append(ctx.hitpoints())
         ctx.close()
-    for k in ("n", "r2", "flux", "ld"):
-        _same(outs[0][k], outs[1][k], k)
+    for o in outs[1:]:
+        for k in ("n", "r2", "flux", "ld"):
+            _same(outs[0][k], o[k], k)
+
+
+def test_tile_ownership_partitions_the_work():
+    """Two contexts that own alternate tiles, fed the same photons, together equal one context."""
+    W, H, M = 64, 48, 20000
+    full = sppm.SppmContext(sppm.make_config(W, H, photons_per_pass=M))
+    parts = [sppm.SppmContext(sppm.make_config(W, H, photons_per_pass=M, tile_first=r, tile_stride=2)) for r in range(2)]
+    for c in [full] + parts:
+        for i in range(2):
+            c.eye_pass(i)
+            c.photon_pass(i, M)
+        c.check()
+    from raytracer_amd.parallel import owner_of_pixels
+    own = owner_of_pixels(W, H, 2)
+    ref = full.hitpoints()
+    got = [c.hitpoints() for c in parts]
+    for k in ("n", "r2", "flux"):
+        merged = np.where(own.reshape((-1,) + (1,) * (ref[k].ndim - 1)) == 0, got[0][k], got[1][k])
+        _same(merged, ref[k], k)
+    for c in [full] + parts:
+        c.close()
 
 
 def test_config1_320x240_matches_oracle():

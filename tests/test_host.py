@@ -64,12 +64,13 @@ def test_create_rejects_bad_arguments():
     assert L.sppm_create(C.byref(cfg), sph, 0, None, C.byref(h)) == -1
 
 
-def test_pixel_slices_partition_the_image():
-    for P in (1, 7, 64 * 48, 1920 * 1080):
+def test_tile_ownership_partitions_the_image():
+    for (w, h) in ((8, 8), (64, 48), (30, 21), (1920, 1080)):
         for world in (1, 2, 3, 8):
-            seen = 0
-            for r in range(world):
-                f, c = parallel.pixel_slice(P, r, world)
-                assert f == seen
-                seen += c
-            assert seen == P
+            own = parallel.owner_of_pixels(w, h, world)
+            assert own.shape == (w * h,) and own.min() >= 0 and own.max() < world
+            # an 8x8 block of pixels never straddles two ranks
+            img = own.reshape(h, w)
+            for r in range(0, h, 8):
+                for c in range(0, w, 8):
+                    assert len(np.unique(img[r:r + 8, c:c + 8])) == 1
