@@ -1,5 +1,8 @@
-// sppm_gather_tiles.hpp -- the tile gather: one wavefront replays, for the 64 hitpoints of an 8x8
-// pixel tile, every photon-hit record near the tile in key (= photon, bounce) order.
+// sppm_gather_tiles.hpp -- the tile gather: one wavefront replays, for a tile of 64 spatially
+// neighbouring hitpoints, every photon-hit record near the tile in key (= photon, bounce) order.
+// Tiles are 64 consecutive hitpoints of this rank's pixels sorted along a Morton curve of their
+// positions (re-sorted after every eye pass): screen-space 8x8 tiles are compact on directly seen
+// diffuse surfaces but scattered over the whole scene behind the mirror and glass spheres.
 //
 // Included by sppm_kernels.hip.  Semantics are exactly those of k_gather (the simple per-hitpoint
 // kernel kept as a cross-check): the search filter of src/kdtree.h:123-127, the acceptance test and
@@ -31,7 +34,8 @@ struct TileParams {
     TileGrid g;
     double gather_r2, alpha;
     int rule;
-    int W, H, tiles_x, n_tiles, tile_first, tile_stride, n_owned;
+    const int32_t* order;  // this rank's image indices, sorted along a Morton curve of the hitpoint positions
+    int n_pix, n_owned;    // entries of order[]; virtual tiles = ceil(n_pix / 64)
     uint64_t* tap_key; int32_t* tap_pix; unsigned long long* tap_n; int64_t tap_cap;
 };
 
@@ -66,6 +70,62 @@ __device__ __forceinline__ int grid_coord(double x, double o, double inv_c, int 
 
 __device__ __forceinline__ int tile_of_pixel(int p, int W, int tiles_x) { return ((p / W) >> 3) * tiles_x + ((p % W) >> 3); }
 
+// ---- spatial order of the hitpoints ------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long ord_d(double v)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double undo_ord_d(unsigned long long o)
+{
+    const unsigned long long b = (o >> 63) ? (o & 0x7fffffffffffffffull) : ~o;
+    return __longlong_as_double((long long)b);
+}
+// bounding box of the valid hitpoints among pix[0..n): bb[0..2] = min, bb[3..5] = max (ordered ints)
+__global__ void k_hp_bbox(HpArrays hp, const int32_t* __restrict__ pix, int n, unsigned long long* __restrict__ bb)
+{
+    const double BIG = 1e300;
+    double lo[3] = {BIG, BIG, BIG}, hi[3] = {-BIG, -BIG, -BIG};
+    const int P = hp.P;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int p = pix[i];
+        if (!hp.valid[p]) continue;
+        for (int a = 0; a < 3; a++) { const double v = hp.pos[a * P + p]; lo[a] = fmin(lo[a], v); hi[a] = fmax(hi[a], v); }
+    }
+    for (int a = 0; a < 3; a++) {
+        for (int off = 32; off > 0; off >>= 1) { lo[a] = fmin(lo[a], __shfl_xor(lo[a], off)); hi[a] = fmax(hi[a], __shfl_xor(hi[a], off)); }
+        if ((threadIdx.x & 63) == 0 && lo[a] <= hi[a]) { atomicMin(&bb[a], ord_d(lo[a])); atomicMax(&bb[3 + a], ord_d(hi[a])); }
+    }
+}
+__device__ __forceinline__ unsigned long long spread3(unsigned long long x)  // 21 bits -> every third bit
+{
+    x &= 0x1fffffull;
+    x = (x | (x << 32)) & 0x1f00000000ffffull;
+    x = (x | (x << 16)) & 0x1f0000ff0000ffull;
+    x = (x | (x << 8)) & 0x100f00f00f00f00full;
+    x = (x | (x << 4)) & 0x10c30c30c30c30c3ull;
+    x = (x | (x << 2)) & 0x1249249249249249ull;
+    return x;
+}
+// 48-bit Morton code (16 bits per axis over the bounding box); invalid hitpoints sort last
+__global__ void k_hp_sortkeys(HpArrays hp, const int32_t* __restrict__ pix, int n, const unsigned long long* __restrict__ bb,
+                              unsigned long long* __restrict__ keys)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int p = pix[i], P = hp.P;
+    if (!hp.valid[p]) { keys[i] = (1ull << 48); return; }
+    unsigned long long code = 0;
+    for (int a = 0; a < 3; a++) {
+        const double lo = undo_ord_d(bb[a]), hi = undo_ord_d(bb[3 + a]);
+        const double ext = hi - lo;
+        double f = ext > 0.0 ? (hp.pos[a * P + p] - lo) / ext * 65535.0 : 0.0;
+        f = f < 0.0 ? 0.0 : (f > 65535.0 ? 65535.0 : f);
+        code |= spread3((unsigned long long)f) << a;
+    }
+    keys[i] = code;
+}
+
 // (slab, cell) bucket of every record of the batch
 __global__ void k_bin_count(RecArrays rec, const unsigned long long* __restrict__ rec_count, TileGrid g, uint32_t* __restrict__ cell_cnt,
                             uint32_t* __restrict__ rec_bucket)
@@ -86,20 +146,15 @@ __global__ void k_bin_count(RecArrays rec, const unsigned long long* __restrict_
 // Global statistics of the owned tiles, to size the grid: bounding box of all hitpoints (ordered-int
 // encoded doubles), a histogram of log2(tile region extent) and the number of live tiles.
 struct TileStats { unsigned long long bb[6]; unsigned int hist[64]; unsigned int live_tiles; unsigned int pad; };
-__device__ __forceinline__ unsigned long long ord_d(double v)
-{
-    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
-    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
-}
 __global__ void __launch_bounds__(256) k_tile_stats(HpArrays hp, TileParams tp, TileStats* __restrict__ st)
 {
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int k = blockIdx.x * 4 + wv;
     if (k >= tp.n_owned) return;
-    const int tile = tp.tile_first + k * tp.tile_stride;
-    const int col = (tile % tp.tiles_x) * 8 + (lane & 7), row = (tile / tp.tiles_x) * 8 + (lane >> 3);
-    const int P = hp.P, p = row * tp.W + col;
-    bool live = (col < tp.W) && (row < tp.H);
+    const int slot = k * 64 + lane;
+    const int P = hp.P;
+    const int p = slot < tp.n_pix ? tp.order[slot] : 0;
+    bool live = slot < tp.n_pix;
     if (live) live = hp.valid[p] != 0;
     if (__ballot(live) == 0) return;
     const double BIG = 1e300;
@@ -130,13 +185,14 @@ __global__ void __launch_bounds__(256) k_gather_tiles(HpArrays hp, DevScene sc, 
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int k = blockIdx.x * 4 + wv;
     if (k >= tp.n_owned) return;
-    const int tile = tp.tile_first + k * tp.tile_stride;
-    const int col = (tile % tp.tiles_x) * 8 + (lane & 7), row = (tile / tp.tiles_x) * 8 + (lane >> 3);
-    const int P = hp.P, p = row * tp.W + col;
-    bool live = (col < tp.W) && (row < tp.H);
+    const int slot = k * 64 + lane;
+    const int P = hp.P;
+    const int p = slot < tp.n_pix ? tp.order[slot] : 0;
+    bool live = slot < tp.n_pix;
     if (live) live = hp.valid[p] != 0;
     if (__ballot(live) == 0) return;
 
+    const unsigned long long t_start = __builtin_amdgcn_s_memtime();
     d3 hpos = mk(0, 0, 0), hn = mk(0, 0, 0), hw = mk(0, 0, 0), hcol = mk(0, 0, 0), acc = mk(0, 0, 0);
     double r2 = 0.0;
     int n = 0, madd = 0;
@@ -320,5 +376,10 @@ __global__ void __launch_bounds__(256) k_gather_tiles(HpArrays hp, DevScene sc, 
         if (c_sel) atomicAdd(&counters[5], (unsigned long long)c_sel);
         if (c_round) atomicAdd(&counters[6], (unsigned long long)c_round);
         atomicAdd(&counters[7], 1ull);  // live tiles
+        // work distribution over tiles (read by the SPPM_DEBUG report only)
+        atomicMax(&counters[8], (unsigned long long)c_sel); atomicMax(&counters[9], (unsigned long long)c_cand);
+        atomicMax(&counters[10], (unsigned long long)c_round);
+        const unsigned long long cyc = (unsigned long long)(__builtin_amdgcn_s_memtime() - t_start);
+        atomicMax(&counters[11], cyc); atomicAdd(&counters[12], cyc);
     }
 }

@@ -17,6 +17,8 @@
 // traced in parallel, and each hitpoint replays "its" photons in key (= photon, bounce) order in
 // registers: exact reference semantics, no atomics on hitpoint data, deterministic.
 #include <hip/hip_runtime.h>
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
 
 #include <algorithm>
 #include <cmath>
@@ -568,6 +570,11 @@ struct sppm_ctx {
     int64_t rec_first, rec_end;  // photon index range of the records in the buffer
     uint64_t photons_applied; // photons gathered so far (sizes the next batch)
     TileStats* d_stats;
+    // spatial order of this rank's hitpoints (tile gather): own pixel list, Morton keys, sorted order
+    int32_t *d_own_pix, *d_order; int n_own_pix;
+    unsigned long long *d_hp_keys, *d_hp_keys_out, *d_hp_bb;
+    void* d_sort_tmp; size_t sort_tmp_bytes;
+    int order_valid;
     sppm_sphere* d_spheres; int ns;
     Camera cam;
     double flux_scale;
@@ -646,7 +653,6 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
     c->tile_stride = cfg->tile_stride > 0 ? cfg->tile_stride : 1;
     c->tile_first = cfg->tile_stride > 0 ? cfg->tile_first : 0;
     if (c->tile_first < 0 || c->tile_first >= c->tile_stride) { delete c; return fail(SPPM_ERR_INVALID, "sppm_create: need 0 <= tile_first < tile_stride"); }
-    c->n_owned = c->tile_first < c->n_tiles ? (c->n_tiles - c->tile_first + c->tile_stride - 1) / c->tile_stride : 0;
     c->gather_mode = (int)env_i64("SPPM_GATHER_TILES", 1);
     c->table_cap = env_i64("SPPM_TABLE_CAP", 1ll << 24);
     if (c->table_cap < 4096) c->table_cap = 4096;
@@ -703,8 +709,34 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
     if (c->gather_mode) nb = (uint32_t)((c->table_cap + SCAN_BLOCK) / SCAN_BLOCK * SCAN_BLOCK);
     TRY(dev_alloc(c, &c->d_cell_cnt, (size_t)nb)); TRY(dev_alloc(c, &c->d_cell_start, (size_t)nb + 1)); TRY(dev_alloc(c, &c->d_cursor, (size_t)nb));
     TRY(dev_alloc(c, &c->d_block_sum, (size_t)nb / SCAN_BLOCK + 1)); TRY(dev_alloc(c, &c->d_total, 1));
-    TRY(dev_alloc(c, &c->d_rec_count, 1)); TRY(dev_alloc(c, &c->d_counters, 8)); TRY(dev_alloc(c, &c->d_r2max, 1)); TRY(dev_alloc(c, &c->d_err, 4));
+    TRY(dev_alloc(c, &c->d_rec_count, 1)); TRY(dev_alloc(c, &c->d_counters, 16)); TRY(dev_alloc(c, &c->d_r2max, 1)); TRY(dev_alloc(c, &c->d_err, 4));
     TRY(dev_alloc(c, &c->d_stats, 1));
+    {   // the image indices this rank owns (8x8 screen tiles dealt round-robin), in index order
+        std::vector<int32_t> own;
+        own.reserve(P / (size_t)c->tile_stride + 64);
+        for (int p = 0; p < c->P; p++) {
+            const int t = ((p / cfg->width) >> 3) * c->tiles_x + ((p % cfg->width) >> 3) - c->tile_first;
+            if (t >= 0 && t % c->tile_stride == 0) own.push_back(p);
+        }
+        c->n_own_pix = (int)own.size();
+        c->n_owned = (c->n_own_pix + 63) / 64;  // virtual tiles of 64 hitpoints
+        TRY(dev_alloc(c, &c->d_own_pix, own.size(), false)); TRY(dev_alloc(c, &c->d_order, own.size(), false));
+        TRY(dev_alloc(c, &c->d_hp_keys, own.size(), false)); TRY(dev_alloc(c, &c->d_hp_keys_out, own.size(), false));
+        TRY(dev_alloc(c, &c->d_hp_bb, 6));
+        if (!own.empty() && hipMemcpy(c->d_own_pix, own.data(), own.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+            sppm_destroy(c); return fail(SPPM_ERR_HIP, "copying the pixel list failed");
+        }
+        c->sort_tmp_bytes = 0; c->d_sort_tmp = nullptr; c->order_valid = 0;
+        if (c->n_own_pix > 0) {
+            if (rocprim::radix_sort_pairs(nullptr, c->sort_tmp_bytes, c->d_hp_keys, c->d_hp_keys_out, c->d_own_pix, c->d_order,
+                                          (size_t)c->n_own_pix, 0, 49, c->stream) != hipSuccess) {
+                sppm_destroy(c); return fail(SPPM_ERR_HIP, "sizing the hitpoint sort failed");
+            }
+            char* tmp = nullptr;
+            TRY(dev_alloc(c, &tmp, c->sort_tmp_bytes, false));
+            c->d_sort_tmp = tmp;
+        }
+    }
 #undef TRY
     if (hipStreamSynchronize(c->stream) != hipSuccess) { sppm_destroy(c); return fail(SPPM_ERR_HIP, "sppm_create: stream sync failed"); }
     *out = c;
@@ -749,6 +781,17 @@ extern "C" int sppm_eye_pass(sppm_ctx* c, int32_t pass)
     ep.pass = pass; ep.seed_eye = c->cfg.seed_eye; ep.initial_r2 = c->cfg.initial_radius2; ep.double_nee = c->cfg.double_nee;
     hipLaunchKernelGGL(k_eye_pass, dim3(nblk(c->P, 256)), dim3(256), 0, c->stream, scene_of(c), ep, c->hp, c->d_counters);
     HIPCHK(hipGetLastError());
+    if (c->gather_mode && c->n_own_pix > 0) {
+        // re-form the gather tiles: sort this rank's hitpoints along a Morton curve of their positions
+        unsigned long long init[6] = {~0ull, ~0ull, ~0ull, 0ull, 0ull, 0ull};
+        HIPCHK(hipMemcpyAsync(c->d_hp_bb, init, sizeof init, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_hp_bbox, dim3(std::min(nblk(c->n_own_pix, 256), 1024)), dim3(256), 0, c->stream, c->hp, c->d_own_pix, c->n_own_pix, c->d_hp_bb);
+        hipLaunchKernelGGL(k_hp_sortkeys, dim3(nblk(c->n_own_pix, 256)), dim3(256), 0, c->stream, c->hp, c->d_own_pix, c->n_own_pix, c->d_hp_bb, c->d_hp_keys);
+        HIPCHK(hipGetLastError());
+        HIPCHK(rocprim::radix_sort_pairs(c->d_sort_tmp, c->sort_tmp_bytes, c->d_hp_keys, c->d_hp_keys_out, c->d_own_pix, c->d_order,
+                                         (size_t)c->n_own_pix, 0, 49, c->stream));
+        c->order_valid = 1;
+    }
     return SPPM_OK;
 }
 
@@ -872,8 +915,8 @@ static int gather_tiles(sppm_ctx* c)
     TileParams tp;
     memset(&tp, 0, sizeof tp);
     tp.gather_r2 = c->cfg.gather_radius2; tp.alpha = c->cfg.alpha; tp.rule = c->cfg.update_rule;
-    tp.W = c->cfg.width; tp.H = c->cfg.height; tp.tiles_x = c->tiles_x; tp.n_tiles = c->n_tiles;
-    tp.tile_first = c->tile_first; tp.tile_stride = c->tile_stride; tp.n_owned = c->n_owned;
+    if (!c->order_valid) return fail(SPPM_ERR_STATE, "sppm_gather: no eye pass has run on this context yet");
+    tp.order = c->d_order; tp.n_pix = c->n_own_pix; tp.n_owned = c->n_owned;
     tp.tap_key = c->d_tap_key; tp.tap_pix = c->d_tap_pix; tp.tap_n = c->d_tap_n; tp.tap_cap = c->tap_cap;
     // --- statistics of the tiles' regions
     TileStats hs;
@@ -881,7 +924,7 @@ static int gather_tiles(sppm_ctx* c)
     hs.bb[0] = hs.bb[1] = hs.bb[2] = ~0ull;
     HIPCHK(hipMemcpyAsync(c->d_stats, &hs, sizeof hs, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_tile_stats, dim3(nblk(c->n_owned, 4)), dim3(256), 0, st, c->hp, tp, c->d_stats);
-    unsigned long long cnt0[8];
+    unsigned long long cnt0[16];
     HIPCHK(hipMemcpyAsync(&hs, c->d_stats, sizeof hs, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(cnt0, c->d_counters, sizeof cnt0, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
@@ -916,11 +959,17 @@ static int gather_tiles(sppm_ctx* c)
     if (rc) return rc;
     hipLaunchKernelGGL(k_grid_scatter, dim3(2048), dim3(256), 0, st, c->rec_u, c->rec_s, c->d_rec_count, c->d_rec_bucket, c->d_cursor);
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (c->timing) { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventRecord(e0, st)); }
+    const bool dbg = getenv("SPPM_DEBUG") != nullptr;
+    if (dbg) { HIPCHK(hipMemsetAsync(c->d_counters + 8, 0, 8 * sizeof(unsigned long long), st)); }
+    if (c->timing || dbg) { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventRecord(e0, st)); }
     hipLaunchKernelGGL(k_gather_tiles, dim3(nblk(c->n_owned, 4)), dim3(256), 0, st, c->hp, scene_of(c), c->rec_s, c->d_cell_start, tp, c->d_counters);
-    if (c->timing) { HIPCHK(hipEventRecord(e1, st)); c->ev.push_back({e0, e1}); }
+    if (c->timing || dbg) { HIPCHK(hipEventRecord(e1, st)); }
     HIPCHK(hipGetLastError());
-    unsigned long long cnt1[8];
+    float dbg_ms = 0.f;
+    if (dbg) { HIPCHK(hipEventSynchronize(e1)); HIPCHK(hipEventElapsedTime(&dbg_ms, e0, e1)); }
+    if (c->timing) c->ev.push_back({e0, e1});
+    else if (dbg) { hipEventDestroy(e0); hipEventDestroy(e1); }
+    unsigned long long cnt1[16];
     HIPCHK(hipMemcpyAsync(cnt1, c->d_counters, sizeof cnt1, hipMemcpyDeviceToHost, st));
     rc = finish_batch(c);  // synchronises
     if (rc) return rc;
@@ -932,9 +981,9 @@ static int gather_tiles(sppm_ctx* c)
         f = std::min(4.0, std::max(0.25, f));
         c->slab_B = std::max<int64_t>(64, (int64_t)((double)B * f));
     }
-    if (getenv("SPPM_DEBUG"))
-        fprintf(stderr, "[sppm] batch %lld photons: cell %.3f grid %dx%dx%d S=%d B=%lld rounds/tile-slab %.2f sel/tile-slab %.2f cand/sel %.2f next B %lld\n",
-                (long long)range, cell, g.nx, g.ny, g.nz, g.S, (long long)B, (double)(cnt1[6] - cnt0[6]) / std::max(1.0, tiles_run * S),
+    if (dbg)
+        fprintf(stderr, "[sppm] batch %lld photons: gather %.2f ms, max per tile: sel %llu cand %llu rounds %llu cycles %llu (avg cycles %.0f); cell %.3f grid %dx%dx%d S=%d B=%lld rounds/tile-slab %.2f sel/tile-slab %.2f cand/sel %.2f next B %lld\n",
+                (long long)range, dbg_ms, cnt1[8], cnt1[9], cnt1[10], cnt1[11], (double)cnt1[12] / std::max(1.0, tiles_run), cell, g.nx, g.ny, g.nz, g.S, (long long)B, (double)(cnt1[6] - cnt0[6]) / std::max(1.0, tiles_run * S),
                 (double)(cnt1[5] - cnt0[5]) / std::max(1.0, tiles_run * S), (double)(cnt1[3] - cnt0[3]) / std::max(1.0, (double)(cnt1[5] - cnt0[5])),
                 (long long)c->slab_B);
     return SPPM_OK;
