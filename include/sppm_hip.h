@@ -143,6 +143,9 @@ int sppm_download_hitpoints(sppm_ctx* ctx, int32_t* h_valid, int32_t* h_obj, dou
  * f[n][9] = position, geometric normal, flux.  Returns the count through n (call with NULL arrays
  * to size). */
 int sppm_download_records(sppm_ctx* ctx, uint64_t* h_key, double* h_f, int64_t* n);
+/* This rank's image indices in gather-tile order (64 consecutive entries form a tile): the Morton
+ * order of the hitpoint positions made by the last eye pass.  Call with NULL to get the count. */
+int sppm_download_tile_order(sppm_ctx* ctx, int32_t* h_order, int64_t* n);
 /* Accepted (record key, image index) pairs of the gathers since the tap was enabled, sorted by
  * (key, index).  Enable with cap > 0 before the photon pass. */
 int sppm_accept_tap(sppm_ctx* ctx, int64_t cap);

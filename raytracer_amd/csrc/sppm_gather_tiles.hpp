@@ -36,6 +36,7 @@ struct TileParams {
     int rule;
     const int32_t* order;  // this rank's image indices, sorted along a Morton curve of the hitpoint positions
     int n_pix, n_owned;    // entries of order[]; virtual tiles = ceil(n_pix / 64)
+    double cluster_d;      // lanes farther than this (max norm) from a tile's seed lane are replayed separately
     uint64_t* tap_key; int32_t* tap_pix; unsigned long long* tap_n; int64_t tap_cap;
 };
 
@@ -128,7 +129,7 @@ __global__ void k_hp_sortkeys(HpArrays hp, const int32_t* __restrict__ pix, int 
 
 // (slab, cell) bucket of every record of the batch
 __global__ void k_bin_count(RecArrays rec, const unsigned long long* __restrict__ rec_count, TileGrid g, uint32_t* __restrict__ cell_cnt,
-                            uint32_t* __restrict__ rec_bucket)
+                            uint32_t* __restrict__ rec_bucket, int32_t* __restrict__ err)
 {
     const int64_t n = min((int64_t)*rec_count, rec.cap);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -136,7 +137,7 @@ __global__ void k_bin_count(RecArrays rec, const unsigned long long* __restrict_
         const int iy = grid_coord(rec.f[rec.cap + i], g.oy, g.inv_c, g.ny);
         const int iz = grid_coord(rec.f[2 * rec.cap + i], g.oz, g.inv_c, g.nz);
         int64_t slab = ((int64_t)(rec.key[i] >> 16) - g.first) / g.B;
-        slab = slab < 0 ? 0 : (slab >= g.S ? g.S - 1 : slab);  // records from outside the batch's photon range stay ordered by key anyway
+        if (slab < 0 || slab >= g.S) { err[3] = 1; slab = slab < 0 ? 0 : g.S - 1; }  // a record outside the declared photon range
         const uint32_t b = (uint32_t)slab * (uint32_t)g.ncells + (uint32_t)((iz * g.ny + iy) * g.nx + ix);
         rec_bucket[i] = b;
         atomicAdd(&cell_cnt[b], 1u);
@@ -177,11 +178,23 @@ __global__ void __launch_bounds__(256) k_tile_stats(HpArrays hp, TileParams tp, 
     }
 }
 
-__global__ void __launch_bounds__(256) k_gather_tiles(HpArrays hp, DevScene sc, RecArrays rec, const uint32_t* __restrict__ cell_start,
-                                                      TileParams tp, unsigned long long* __restrict__ counters)
+// ---- work items: (tile, lane range) ---------------------------------------------------------------------
+// Record density is very uneven (caustics, the gap between the light and the ceiling hold a few
+// percent of all records in a few square units).  A tile there has ~100x the average work, and a tile
+// is replayed by ONE wavefront, so it would set the kernel's duration.  k_tile_est counts the records
+// in each tile's cells; k_tile_emit cuts tiles that exceed a threshold into 2..64 contiguous lane
+// ranges (consecutive lanes are consecutive on the Morton curve, so a range is compact and its region
+// smaller); each range becomes a work item replayed by its own wavefront.  Results do not depend on
+// the cut: every hitpoint still sees every record near it, in key order.
+__device__ __forceinline__ uint32_t pack_item(int tile, int lane0, int lanes) { return ((uint32_t)tile << 12) | ((uint32_t)lane0 << 6) | (uint32_t)(lanes - 1); }
+
+// One wavefront per tile: count the records in the cells of the tile's region; if that exceeds the
+// threshold, halve the lane range and look at each half's own (smaller) region, down to single lanes.
+__global__ void __launch_bounds__(256) k_tile_plan(HpArrays hp, const uint32_t* __restrict__ cell_start, TileParams tp, uint32_t threshold,
+                                                   uint32_t* __restrict__ items, unsigned int* __restrict__ n_items,
+                                                   unsigned long long* __restrict__ est_sum)
 {
-    __shared__ unsigned long long s_key[4][64];
-    __shared__ uint32_t s_rec[4][64];
+    __shared__ uint32_t s_stack[4][16];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int k = blockIdx.x * 4 + wv;
     if (k >= tp.n_owned) return;
@@ -189,6 +202,65 @@ __global__ void __launch_bounds__(256) k_gather_tiles(HpArrays hp, DevScene sc, 
     const int P = hp.P;
     const int p = slot < tp.n_pix ? tp.order[slot] : 0;
     bool live = slot < tp.n_pix;
+    if (live) live = hp.valid[p] != 0;
+    if (__ballot(live) == 0) return;
+    const double BIG = 1e300;
+    const double x = live ? hp.pos[p] : 0.0, y = live ? hp.pos[P + p] : 0.0, z = live ? hp.pos[2 * P + p] : 0.0;
+    const double rr = live ? sqrt(fmin(hp.r2[p], tp.gather_r2)) * (1.0 + 1e-9) + 1e-9 : 0.0;
+    int sp = 0;
+    if (lane == 0) s_stack[wv][0] = (0u << 8) | 64u;  // (first lane, lanes)
+    sp = 1;
+    bool first = true;
+    while (sp > 0) {
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t top = s_stack[wv][sp - 1];
+        __builtin_amdgcn_wave_barrier();
+        sp--;
+        const int a = (int)(top >> 8), len = (int)(top & 0xffu);
+        const bool in = live && lane >= a && lane < a + len;
+        if (__ballot(in) == 0) continue;
+        const double rm = wave_max_d(in ? rr : 0.0);
+        const int cx0 = grid_coord(wave_min_d(in ? x : BIG) - rm, tp.g.ox, tp.g.inv_c, tp.g.nx), cx1 = grid_coord(wave_max_d(in ? x : -BIG) + rm, tp.g.ox, tp.g.inv_c, tp.g.nx);
+        const int cy0 = grid_coord(wave_min_d(in ? y : BIG) - rm, tp.g.oy, tp.g.inv_c, tp.g.ny), cy1 = grid_coord(wave_max_d(in ? y : -BIG) + rm, tp.g.oy, tp.g.inv_c, tp.g.ny);
+        const int cz0 = grid_coord(wave_min_d(in ? z : BIG) - rm, tp.g.oz, tp.g.inv_c, tp.g.nz), cz1 = grid_coord(wave_max_d(in ? z : -BIG) + rm, tp.g.oz, tp.g.inv_c, tp.g.nz);
+        const int kx = cx1 - cx0 + 1, ky = cy1 - cy0 + 1, kz = cz1 - cz0 + 1;
+        const int Ktot = kx * ky * kz;
+        unsigned int sum = 0;
+        for (int q = lane; q < Ktot; q += 64) {
+            const int ix = cx0 + q % kx, iy = cy0 + (q / kx) % ky, iz = cz0 + q / (kx * ky);
+            const uint32_t cell = (uint32_t)((iz * tp.g.ny + iy) * tp.g.nx + ix);
+            for (int s = 0; s < tp.g.S; s++) {
+                const uint32_t b = (uint32_t)s * (uint32_t)tp.g.ncells + cell;
+                sum += cell_start[b + 1] - cell_start[b];
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+        sum = (unsigned int)__builtin_amdgcn_readfirstlane((int)sum);
+        if (first) { if (lane == 0) atomicAdd(est_sum, (unsigned long long)sum); first = false; }
+        if (sum <= threshold || len == 1) {
+            if (lane == 0) items[atomicAdd(n_items, 1u)] = pack_item(k, a, len);
+        } else {
+            if (lane == 0) { s_stack[wv][sp] = ((uint32_t)(a + len / 2) << 8) | (uint32_t)(len / 2); s_stack[wv][sp + 1] = ((uint32_t)a << 8) | (uint32_t)(len / 2); }
+            sp += 2;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_gather_tiles(HpArrays hp, DevScene sc, RecArrays rec, const uint32_t* __restrict__ cell_start,
+                                                      TileParams tp, const uint32_t* __restrict__ items, const unsigned int* __restrict__ n_items,
+                                                      unsigned long long* __restrict__ counters)
+{
+    __shared__ unsigned long long s_key[4][64];
+    __shared__ uint32_t s_rec[4][64];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const unsigned int item_i = blockIdx.x * 4 + wv;
+    if (item_i >= *n_items) return;
+    const uint32_t item = items[item_i];
+    const int k = (int)(item >> 12), lane0 = (int)((item >> 6) & 63u), lanes = (int)(item & 63u) + 1;
+    const int slot = k * 64 + lane;
+    const int P = hp.P;
+    const int p = slot < tp.n_pix ? tp.order[slot] : 0;
+    bool live = slot < tp.n_pix && lane >= lane0 && lane < lane0 + lanes;
     if (live) live = hp.valid[p] != 0;
     if (__ballot(live) == 0) return;
 
@@ -206,18 +278,28 @@ __global__ void __launch_bounds__(256) k_gather_tiles(HpArrays hp, DevScene sc, 
         else { madd = hp.madd[p]; acc = mk(hp.phi[p], hp.phi[P + p], hp.phi[2 * P + p]); }
     }
     const double BIG = 1e300;
-    const double bx0 = wave_min_d(live ? hpos.x : BIG), bx1 = wave_max_d(live ? hpos.x : -BIG);
-    const double by0 = wave_min_d(live ? hpos.y : BIG), by1 = wave_max_d(live ? hpos.y : -BIG);
-    const double bz0 = wave_min_d(live ? hpos.z : BIG), bz1 = wave_max_d(live ? hpos.z : -BIG);
     const double thr = tp.gather_r2 * 0.01;
     const double band_rel = 1e-9 + 8e-15 / thr;
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const int64_t cap = rec.cap;
     unsigned int c_cand = 0, c_sel = 0, c_acc = 0, c_round = 0;  // wave-uniform tallies except c_acc (per lane)
 
+    // A tile is 64 consecutive hitpoints of the Morton order, which is compact except where the curve
+    // jumps (or where a surface ends).  Lanes far from the seed lane are replayed as a cluster of
+    // their own, so that a scattered tile costs the sum of its parts and not their bounding box.
+    unsigned long long remaining = __ballot(live);
+    while (remaining) {
+    const int seed = __ffsll((long long)remaining) - 1;
+    const double sx = rl_d(hpos.x, seed), sy = rl_d(hpos.y, seed), sz = rl_d(hpos.z, seed);
+    const bool inc = live && ((remaining >> lane) & 1ull) && fabs(hpos.x - sx) <= tp.cluster_d && fabs(hpos.y - sy) <= tp.cluster_d &&
+                     fabs(hpos.z - sz) <= tp.cluster_d;
+    remaining &= ~__ballot(inc);
+    const double bx0 = wave_min_d(inc ? hpos.x : BIG), bx1 = wave_max_d(inc ? hpos.x : -BIG);
+    const double by0 = wave_min_d(inc ? hpos.y : BIG), by1 = wave_max_d(inc ? hpos.y : -BIG);
+    const double bz0 = wave_min_d(inc ? hpos.z : BIG), bz1 = wave_max_d(inc ? hpos.z : -BIG);
     for (int s = 0; s < tp.g.S; s++) {
         // region of this slab: bounding box grown by the largest radius any lane can still accept at
-        const double rr = live ? sqrt(fmin(r2, tp.gather_r2)) * (1.0 + 1e-9) + 1e-9 : 0.0;
+        const double rr = inc ? sqrt(fmin(r2, tp.gather_r2)) * (1.0 + 1e-9) + 1e-9 : 0.0;
         const double rmax = wave_max_d(rr);
         const double lx = bx0 - rmax, hx = bx1 + rmax, ly = by0 - rmax, hy = by1 + rmax, lz = bz0 - rmax, hz = bz1 + rmax;
         const int cx0 = __builtin_amdgcn_readfirstlane(grid_coord(lx, tp.g.ox, tp.g.inv_c, tp.g.nx));
@@ -229,8 +311,8 @@ __global__ void __launch_bounds__(256) k_gather_tiles(HpArrays hp, DevScene sc, 
         const int kx = cx1 - cx0 + 1, ky = cy1 - cy0 + 1, kz = cz1 - cz0 + 1;
         const int Ktot = kx * ky * kz;
         const uint32_t slab_base = (uint32_t)s * (uint32_t)tp.g.ncells;
-        const unsigned long long kend = (s == tp.g.S - 1) ? ~0ull : ((unsigned long long)(tp.g.first + (int64_t)(s + 1) * tp.g.B) << 16);
-        unsigned long long klo = (s == 0) ? 0ull : ((unsigned long long)(tp.g.first + (int64_t)s * tp.g.B) << 16);
+        const unsigned long long kend = (unsigned long long)(tp.g.first + (int64_t)(s + 1) * tp.g.B) << 16;
+        unsigned long long klo = (unsigned long long)(tp.g.first + (int64_t)s * tp.g.B) << 16;
         unsigned long long khi = kend;
         while (klo < kend) {
             // ---- collect the candidates with key in [klo, khi) inside the region into LDS (at most 64)
@@ -308,7 +390,7 @@ __global__ void __launch_bounds__(256) k_gather_tiles(HpArrays hp, DevScene sc, 
                     const d3 qq = mk(rl_d(q.x, src), rl_d(q.y, src), rl_d(q.z, src));
                     const d3 dir = hpos - qq;
                     const double d2 = len2(dir);
-                    bool ok = live && (d2 < tp.gather_r2) && (d2 <= r2);
+                    bool ok = inc && (d2 < tp.gather_r2) && (d2 <= r2);
                     if (__ballot(ok) == 0) continue;
                     const d3 g0 = mk(rl_d(gn.x, src), rl_d(gn.y, src), rl_d(gn.z, src));
                     ok = ok && (dot(hn, g0) > 1e-3);
@@ -360,6 +442,7 @@ __global__ void __launch_bounds__(256) k_gather_tiles(HpArrays hp, DevScene sc, 
             khi = kend;
         }
     }
+    }  // clusters
     if (live) {
         if (tp.rule == 0) {
             hp.r2[p] = r2; hp.n[p] = n;
@@ -381,5 +464,6 @@ __global__ void __launch_bounds__(256) k_gather_tiles(HpArrays hp, DevScene sc, 
         atomicMax(&counters[10], (unsigned long long)c_round);
         const unsigned long long cyc = (unsigned long long)(__builtin_amdgcn_s_memtime() - t_start);
         atomicMax(&counters[11], cyc); atomicAdd(&counters[12], cyc);
+        atomicMax(&counters[13], ((unsigned long long)c_sel << 24) | (unsigned long long)k);
     }
 }

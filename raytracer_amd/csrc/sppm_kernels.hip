@@ -574,6 +574,8 @@ struct sppm_ctx {
     int32_t *d_own_pix, *d_order; int n_own_pix;
     unsigned long long *d_hp_keys, *d_hp_keys_out, *d_hp_bb;
     void* d_sort_tmp; size_t sort_tmp_bytes;
+    uint32_t *d_est, *d_items; unsigned int* d_n_items; unsigned long long* d_est_sum;
+    double split_factor, est_per_photon;
     int order_valid;
     sppm_sphere* d_spheres; int ns;
     Camera cam;
@@ -727,6 +729,10 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
             sppm_destroy(c); return fail(SPPM_ERR_HIP, "copying the pixel list failed");
         }
         c->sort_tmp_bytes = 0; c->d_sort_tmp = nullptr; c->order_valid = 0;
+        TRY(dev_alloc(c, &c->d_est, (size_t)c->n_owned + 1)); TRY(dev_alloc(c, &c->d_items, (size_t)c->n_owned * 64 + 64, false));
+        TRY(dev_alloc(c, &c->d_n_items, 1)); TRY(dev_alloc(c, &c->d_est_sum, 1));
+        c->split_factor = 4.0; c->est_per_photon = 0.0;
+        { const char* e = getenv("SPPM_SPLIT_FACTOR"); if (e && *e) c->split_factor = atof(e); }
         if (c->n_own_pix > 0) {
             if (rocprim::radix_sort_pairs(nullptr, c->sort_tmp_bytes, c->d_hp_keys, c->d_hp_keys_out, c->d_own_pix, c->d_order,
                                           (size_t)c->n_own_pix, 0, 49, c->stream) != hipSuccess) {
@@ -951,18 +957,33 @@ static int gather_tiles(sppm_ctx* c)
     g.nx = (int)dims[0]; g.ny = (int)dims[1]; g.nz = (int)dims[2]; g.ncells = (int)ncells;
     g.S = (int)S; g.B = B; g.first = c->rec_first;
     tp.g = g;
+    tp.cluster_d = std::ldexp(1.0, med - 32);  // upper edge of the median tile extent
     const uint32_t n_table = (uint32_t)(S * ncells);
     const uint32_t n_padded = (n_table + SCAN_BLOCK - 1) / SCAN_BLOCK * SCAN_BLOCK;
     HIPCHK(hipMemsetAsync(c->d_cell_cnt, 0, sizeof(uint32_t) * n_padded, st));
-    hipLaunchKernelGGL(k_bin_count, dim3(2048), dim3(256), 0, st, c->rec_u, c->d_rec_count, g, c->d_cell_cnt, c->d_rec_bucket);
+    hipLaunchKernelGGL(k_bin_count, dim3(2048), dim3(256), 0, st, c->rec_u, c->d_rec_count, g, c->d_cell_cnt, c->d_rec_bucket, c->d_err);
     int rc = run_scan(c, n_padded);
     if (rc) return rc;
     hipLaunchKernelGGL(k_grid_scatter, dim3(2048), dim3(256), 0, st, c->rec_u, c->rec_s, c->d_rec_count, c->d_rec_bucket, c->d_cursor);
+    // --- work items: cut tiles whose region holds far more records than the average tile's.  The
+    // threshold comes from the previous batch's mean (scaled by the photon count); the first batch is not cut.
+    HIPCHK(hipMemsetAsync(c->d_est_sum, 0, sizeof(unsigned long long), st));
+    HIPCHK(hipMemsetAsync(c->d_n_items, 0, sizeof(unsigned int), st));
+    const double thr_d = c->est_per_photon > 0.0 ? std::max(256.0, c->est_per_photon * (double)range * c->split_factor) : 4.0e9;
+    const uint32_t split_thr = (uint32_t)std::min(4.0e9, thr_d);
+    hipLaunchKernelGGL(k_tile_plan, dim3(nblk(c->n_owned, 4)), dim3(256), 0, st, c->hp, c->d_cell_start, tp, split_thr, c->d_items, c->d_n_items, c->d_est_sum);
+    unsigned long long est_sum = 0;
+    unsigned int n_items = 0;
+    HIPCHK(hipMemcpyAsync(&est_sum, c->d_est_sum, sizeof est_sum, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&n_items, c->d_n_items, sizeof n_items, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    const double mean_est = (double)est_sum / (double)hs.live_tiles;
+    c->est_per_photon = mean_est / (double)range;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     const bool dbg = getenv("SPPM_DEBUG") != nullptr;
     if (dbg) { HIPCHK(hipMemsetAsync(c->d_counters + 8, 0, 8 * sizeof(unsigned long long), st)); }
     if (c->timing || dbg) { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventRecord(e0, st)); }
-    hipLaunchKernelGGL(k_gather_tiles, dim3(nblk(c->n_owned, 4)), dim3(256), 0, st, c->hp, scene_of(c), c->rec_s, c->d_cell_start, tp, c->d_counters);
+    hipLaunchKernelGGL(k_gather_tiles, dim3(nblk(n_items, 4)), dim3(256), 0, st, c->hp, scene_of(c), c->rec_s, c->d_cell_start, tp, c->d_items, c->d_n_items, c->d_counters);
     if (c->timing || dbg) { HIPCHK(hipEventRecord(e1, st)); }
     HIPCHK(hipGetLastError());
     float dbg_ms = 0.f;
@@ -982,10 +1003,30 @@ static int gather_tiles(sppm_ctx* c)
         c->slab_B = std::max<int64_t>(64, (int64_t)((double)B * f));
     }
     if (dbg)
-        fprintf(stderr, "[sppm] batch %lld photons: gather %.2f ms, max per tile: sel %llu cand %llu rounds %llu cycles %llu (avg cycles %.0f); cell %.3f grid %dx%dx%d S=%d B=%lld rounds/tile-slab %.2f sel/tile-slab %.2f cand/sel %.2f next B %lld\n",
-                (long long)range, dbg_ms, cnt1[8], cnt1[9], cnt1[10], cnt1[11], (double)cnt1[12] / std::max(1.0, tiles_run), cell, g.nx, g.ny, g.nz, g.S, (long long)B, (double)(cnt1[6] - cnt0[6]) / std::max(1.0, tiles_run * S),
+        fprintf(stderr, "[sppm] batch %lld photons: %u items for %d tiles (mean est %.0f), gather %.2f ms, max per tile: sel %llu cand %llu rounds %llu cycles %llu (avg cycles %.0f); cell %.3f grid %dx%dx%d S=%d B=%lld rounds/tile-slab %.2f sel/tile-slab %.2f cand/sel %.2f next B %lld\n",
+                (long long)range, n_items, c->n_owned, mean_est, dbg_ms, cnt1[8], cnt1[9], cnt1[10], cnt1[11], (double)cnt1[12] / std::max(1.0, tiles_run), cell, g.nx, g.ny, g.nz, g.S, (long long)B, (double)(cnt1[6] - cnt0[6]) / std::max(1.0, tiles_run * S),
                 (double)(cnt1[5] - cnt0[5]) / std::max(1.0, tiles_run * S), (double)(cnt1[3] - cnt0[3]) / std::max(1.0, (double)(cnt1[5] - cnt0[5])),
                 (long long)c->slab_B);
+    if (dbg) {
+        const int hk = (int)(cnt1[13] & 0xffffff);
+        std::vector<int32_t> ord(64), obj(64);
+        const int nn = std::min(64, c->n_own_pix - hk * 64);
+        hipMemcpy(ord.data(), c->d_order + (size_t)hk * 64, nn * 4, hipMemcpyDeviceToHost);
+        double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300}, rmin = 1e300, rmax = 0;
+        int objs[16] = {0};
+        for (int i = 0; i < nn; i++) {
+            double v[3], r2; int32_t o, val;
+            hipMemcpy(&val, c->hp.valid + ord[i], 4, hipMemcpyDeviceToHost);
+            if (!val) continue;
+            for (int a = 0; a < 3; a++) { hipMemcpy(&v[a], c->hp.pos + (size_t)a * c->P + ord[i], 8, hipMemcpyDeviceToHost); mn[a] = std::min(mn[a], v[a]); mx[a] = std::max(mx[a], v[a]); }
+            hipMemcpy(&r2, c->hp.r2 + ord[i], 8, hipMemcpyDeviceToHost); rmin = std::min(rmin, r2); rmax = std::max(rmax, r2);
+            hipMemcpy(&o, c->hp.obj + ord[i], 4, hipMemcpyDeviceToHost); if (o >= 0 && o < 16) objs[o]++;
+        }
+        uint32_t hest = 0;
+        fprintf(stderr, "[sppm]   est %u thr %u; heaviest tile %d (sel %llu): bbox [%.2f %.2f %.2f]-[%.2f %.2f %.2f] r2 %.4f..%.4f objs", hest, split_thr, hk, cnt1[13] >> 24, mn[0], mn[1], mn[2], mx[0], mx[1], mx[2], rmin, rmax);
+        for (int o = 0; o < 16; o++) if (objs[o]) fprintf(stderr, " %d:%d", o, objs[o]);
+        fprintf(stderr, "\n");
+    }
     return SPPM_OK;
 }
 
@@ -1112,6 +1153,7 @@ extern "C" int sppm_check(sppm_ctx* c)
     if (err[0]) return fail(SPPM_ERR_OVERFLOW, "record buffer overflow: raise SPPM_RECORD_CAP or lower SPPM_BATCH_PHOTONS");
     if (err[1]) return fail(SPPM_ERR_OVERFLOW, "a photon path exceeded 32767 bounces");
     if (err[2]) return fail(SPPM_ERR_OVERFLOW, "a query exceeded gather_max (the K cap is not implemented)");
+    if (err[3]) return fail(SPPM_ERR_STATE, "a record's photon index lies outside the range declared for the batch");
     return SPPM_OK;
 }
 
@@ -1177,6 +1219,17 @@ extern "C" int sppm_download_records(sppm_ctx* c, uint64_t* h_key, double* h_f, 
         if (h_key) h_key[i] = key[order[i]];
         if (h_f) for (int k = 0; k < 9; k++) h_f[9 * i + k] = f[(size_t)k * cnt + order[i]];
     }
+    return SPPM_OK;
+}
+
+extern "C" int sppm_download_tile_order(sppm_ctx* c, int32_t* h_order, int64_t* n)
+{
+    if (!c || !n) return fail(SPPM_ERR_INVALID, "sppm_download_tile_order: null argument");
+    *n = c->n_own_pix;
+    if (!h_order) return SPPM_OK;
+    if (!c->order_valid) return fail(SPPM_ERR_STATE, "sppm_download_tile_order: no eye pass has run yet");
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(h_order, c->d_order, (size_t)c->n_own_pix * 4, hipMemcpyDeviceToHost));
     return SPPM_OK;
 }
 

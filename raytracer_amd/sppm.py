@@ -145,6 +145,13 @@ class SppmContext:
         capi.check(self.L.sppm_download_records(self.h, key.ctypes.data, f.ctypes.data, C.byref(n)))
         return key, f
 
+    def tile_order(self):
+        n = C.c_int64()
+        capi.check(self.L.sppm_download_tile_order(self.h, None, C.byref(n)))
+        out = np.zeros(n.value, np.int32)
+        capi.check(self.L.sppm_download_tile_order(self.h, out.ctypes.data, C.byref(n)))
+        return out
+
     def accept_tap(self, cap):
         capi.check(self.L.sppm_accept_tap(self.h, cap))
 
