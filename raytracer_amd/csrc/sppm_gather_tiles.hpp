@@ -246,6 +246,7 @@ __global__ void __launch_bounds__(256) k_tile_plan(HpArrays hp, const uint32_t* 
     }
 }
 
+template <bool STAMPS>
 __global__ void __launch_bounds__(256) k_gather_tiles(HpArrays hp, DevScene sc, RecArrays rec, const uint32_t* __restrict__ cell_start,
                                                       TileParams tp, const uint32_t* __restrict__ items, const unsigned int* __restrict__ n_items,
                                                       unsigned long long* __restrict__ counters)
@@ -283,6 +284,8 @@ __global__ void __launch_bounds__(256) k_gather_tiles(HpArrays hp, DevScene sc, 
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const int64_t cap = rec.cap;
     unsigned int c_cand = 0, c_sel = 0, c_acc = 0, c_round = 0;  // wave-uniform tallies except c_acc (per lane)
+    unsigned long long st_scan = 0, st_rank = 0, st_apply = 0;   // diagnostic build only (STAMPS)
+#define TSTAMP() (STAMPS ? (unsigned long long)__builtin_amdgcn_s_memtime() : 0ull)
 
     // A tile is 64 consecutive hitpoints of the Morton order, which is compact except where the curve
     // jumps (or where a surface ends).  Lanes far from the seed lane are replayed as a cluster of
@@ -318,6 +321,7 @@ __global__ void __launch_bounds__(256) k_gather_tiles(HpArrays hp, DevScene sc, 
             // ---- collect the candidates with key in [klo, khi) inside the region into LDS (at most 64)
             int sel_n = 0;
             bool overflow = false;
+            const unsigned long long ts0 = TSTAMP();
             for (int qbase = 0; qbase < Ktot && !overflow; qbase += 64) {
                 const int q = qbase + lane;
                 uint32_t cs = 0, cn = 0;
@@ -364,6 +368,8 @@ __global__ void __launch_bounds__(256) k_gather_tiles(HpArrays hp, DevScene sc, 
                     sel_n += cnt;
                 }
             }
+            const unsigned long long ts1 = TSTAMP();
+            st_scan += ts1 - ts0;
             if (overflow) { khi = klo + (khi - klo) / 2; continue; }
             if (sel_n > 0) {
                 __builtin_amdgcn_wave_barrier();
@@ -383,6 +389,8 @@ __global__ void __launch_bounds__(256) k_gather_tiles(HpArrays hp, DevScene sc, 
                 int rank = 0;
                 for (int jj = 0; jj < sel_n; jj++) rank += (s_key[wv][jj] < mykey) ? 1 : 0;
                 __builtin_amdgcn_wave_barrier();
+                const unsigned long long ts2 = TSTAMP();
+                st_rank += ts2 - ts1;
                 // ---- apply in key order
                 for (int t = 0; t < sel_n; t++) {
                     const unsigned long long ms = __ballot(own && rank == t);
@@ -437,6 +445,7 @@ __global__ void __launch_bounds__(256) k_gather_tiles(HpArrays hp, DevScene sc, 
                         }
                     }
                 }
+                st_apply += TSTAMP() - ts2;
             }
             klo = khi;
             khi = kend;
@@ -465,5 +474,7 @@ __global__ void __launch_bounds__(256) k_gather_tiles(HpArrays hp, DevScene sc, 
         const unsigned long long cyc = (unsigned long long)(__builtin_amdgcn_s_memtime() - t_start);
         atomicMax(&counters[11], cyc); atomicAdd(&counters[12], cyc);
         atomicMax(&counters[13], ((unsigned long long)c_sel << 24) | (unsigned long long)k);
+        if (STAMPS) { atomicAdd(&counters[16], st_scan); atomicAdd(&counters[17], st_rank); atomicAdd(&counters[18], st_apply); }
     }
+#undef TSTAMP
 }

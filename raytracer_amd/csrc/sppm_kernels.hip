@@ -711,7 +711,7 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
     if (c->gather_mode) nb = (uint32_t)((c->table_cap + SCAN_BLOCK) / SCAN_BLOCK * SCAN_BLOCK);
     TRY(dev_alloc(c, &c->d_cell_cnt, (size_t)nb)); TRY(dev_alloc(c, &c->d_cell_start, (size_t)nb + 1)); TRY(dev_alloc(c, &c->d_cursor, (size_t)nb));
     TRY(dev_alloc(c, &c->d_block_sum, (size_t)nb / SCAN_BLOCK + 1)); TRY(dev_alloc(c, &c->d_total, 1));
-    TRY(dev_alloc(c, &c->d_rec_count, 1)); TRY(dev_alloc(c, &c->d_counters, 16)); TRY(dev_alloc(c, &c->d_r2max, 1)); TRY(dev_alloc(c, &c->d_err, 4));
+    TRY(dev_alloc(c, &c->d_rec_count, 1)); TRY(dev_alloc(c, &c->d_counters, 24)); TRY(dev_alloc(c, &c->d_r2max, 1)); TRY(dev_alloc(c, &c->d_err, 4));
     TRY(dev_alloc(c, &c->d_stats, 1));
     {   // the image indices this rank owns (8x8 screen tiles dealt round-robin), in index order
         std::vector<int32_t> own;
@@ -930,7 +930,7 @@ static int gather_tiles(sppm_ctx* c)
     hs.bb[0] = hs.bb[1] = hs.bb[2] = ~0ull;
     HIPCHK(hipMemcpyAsync(c->d_stats, &hs, sizeof hs, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_tile_stats, dim3(nblk(c->n_owned, 4)), dim3(256), 0, st, c->hp, tp, c->d_stats);
-    unsigned long long cnt0[16];
+    unsigned long long cnt0[24];
     HIPCHK(hipMemcpyAsync(&hs, c->d_stats, sizeof hs, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(cnt0, c->d_counters, sizeof cnt0, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
@@ -981,16 +981,19 @@ static int gather_tiles(sppm_ctx* c)
     c->est_per_photon = mean_est / (double)range;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     const bool dbg = getenv("SPPM_DEBUG") != nullptr;
-    if (dbg) { HIPCHK(hipMemsetAsync(c->d_counters + 8, 0, 8 * sizeof(unsigned long long), st)); }
+    if (dbg) { HIPCHK(hipMemsetAsync(c->d_counters + 8, 0, 16 * sizeof(unsigned long long), st)); }
     if (c->timing || dbg) { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventRecord(e0, st)); }
-    hipLaunchKernelGGL(k_gather_tiles, dim3(nblk(n_items, 4)), dim3(256), 0, st, c->hp, scene_of(c), c->rec_s, c->d_cell_start, tp, c->d_items, c->d_n_items, c->d_counters);
+    if (getenv("SPPM_STAMPS"))
+        hipLaunchKernelGGL(k_gather_tiles<true>, dim3(nblk(n_items, 4)), dim3(256), 0, st, c->hp, scene_of(c), c->rec_s, c->d_cell_start, tp, c->d_items, c->d_n_items, c->d_counters);
+    else
+        hipLaunchKernelGGL(k_gather_tiles<false>, dim3(nblk(n_items, 4)), dim3(256), 0, st, c->hp, scene_of(c), c->rec_s, c->d_cell_start, tp, c->d_items, c->d_n_items, c->d_counters);
     if (c->timing || dbg) { HIPCHK(hipEventRecord(e1, st)); }
     HIPCHK(hipGetLastError());
     float dbg_ms = 0.f;
     if (dbg) { HIPCHK(hipEventSynchronize(e1)); HIPCHK(hipEventElapsedTime(&dbg_ms, e0, e1)); }
     if (c->timing) c->ev.push_back({e0, e1});
     else if (dbg) { hipEventDestroy(e0); hipEventDestroy(e1); }
-    unsigned long long cnt1[16];
+    unsigned long long cnt1[24];
     HIPCHK(hipMemcpyAsync(cnt1, c->d_counters, sizeof cnt1, hipMemcpyDeviceToHost, st));
     rc = finish_batch(c);  // synchronises
     if (rc) return rc;
@@ -1007,6 +1010,9 @@ static int gather_tiles(sppm_ctx* c)
                 (long long)range, n_items, c->n_owned, mean_est, dbg_ms, cnt1[8], cnt1[9], cnt1[10], cnt1[11], (double)cnt1[12] / std::max(1.0, tiles_run), cell, g.nx, g.ny, g.nz, g.S, (long long)B, (double)(cnt1[6] - cnt0[6]) / std::max(1.0, tiles_run * S),
                 (double)(cnt1[5] - cnt0[5]) / std::max(1.0, tiles_run * S), (double)(cnt1[3] - cnt0[3]) / std::max(1.0, (double)(cnt1[5] - cnt0[5])),
                 (long long)c->slab_B);
+    if (dbg && getenv("SPPM_STAMPS"))
+        fprintf(stderr, "[sppm]   stamps (share of item cycles): scan %.1f%% rank+load %.1f%% apply %.1f%%\n", 100.0 * cnt1[16] / std::max(1.0, (double)cnt1[12]),
+                100.0 * cnt1[17] / std::max(1.0, (double)cnt1[12]), 100.0 * cnt1[18] / std::max(1.0, (double)cnt1[12]));
     if (dbg) {
         const int hk = (int)(cnt1[13] & 0xffffff);
         std::vector<int32_t> ord(64), obj(64);
