@@ -146,8 +146,9 @@ __global__ void k_bin_count(RecArrays rec, const unsigned long long* __restrict_
 
 // Global statistics of the owned tiles, to size the grid: bounding box of all hitpoints (ordered-int
 // encoded doubles), a histogram of log2(tile region extent) and the number of live tiles.
-struct TileStats { unsigned long long bb[6]; unsigned int hist[64]; unsigned int live_tiles; unsigned int pad; };
-__global__ void __launch_bounds__(256) k_tile_stats(HpArrays hp, TileParams tp, TileStats* __restrict__ st)
+struct TileStats { unsigned int hist[64]; unsigned int live_tiles; unsigned int pad; unsigned long long est_sum; };
+// extent (largest bounding-box side + twice the largest radius) of every tile, as log2 bin + 1 (0 = no live lane)
+__global__ void __launch_bounds__(256) k_tile_extent(HpArrays hp, TileParams tp, uint8_t* __restrict__ ext_bin)
 {
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int k = blockIdx.x * 4 + wv;
@@ -157,7 +158,7 @@ __global__ void __launch_bounds__(256) k_tile_stats(HpArrays hp, TileParams tp, 
     const int p = slot < tp.n_pix ? tp.order[slot] : 0;
     bool live = slot < tp.n_pix;
     if (live) live = hp.valid[p] != 0;
-    if (__ballot(live) == 0) return;
+    if (__ballot(live) == 0) { if (lane == 0) ext_bin[k] = 0; return; }
     const double BIG = 1e300;
     const double x = live ? hp.pos[p] : 0.0, y = live ? hp.pos[P + p] : 0.0, z = live ? hp.pos[2 * P + p] : 0.0;
     const double r = live ? sqrt(fmin(hp.r2[p], tp.gather_r2)) : 0.0;
@@ -170,12 +171,30 @@ __global__ void __launch_bounds__(256) k_tile_stats(HpArrays hp, TileParams tp, 
         int e;
         frexp(ext, &e);  // ext in [2^(e-1), 2^e)
         e = e + 32;
-        e = e < 0 ? 0 : (e > 63 ? 63 : e);
-        atomicAdd(&st->hist[e], 1u);
-        atomicAdd(&st->live_tiles, 1u);
-        atomicMin(&st->bb[0], ord_d(x0 - rm)); atomicMin(&st->bb[1], ord_d(y0 - rm)); atomicMin(&st->bb[2], ord_d(z0 - rm));
-        atomicMax(&st->bb[3], ord_d(x1 + rm)); atomicMax(&st->bb[4], ord_d(y1 + rm)); atomicMax(&st->bb[5], ord_d(z1 + rm));
+        e = e < 0 ? 0 : (e > 62 ? 62 : e);
+        ext_bin[k] = (uint8_t)(e + 1);
     }
+}
+// one block: histogram of the tile extents, and the sum of the per-tile record estimates of the last plan
+__global__ void __launch_bounds__(1024) k_tile_hist(const uint8_t* __restrict__ ext_bin, const uint32_t* __restrict__ est, int n, TileStats* __restrict__ st)
+{
+    __shared__ unsigned int h[64];
+    __shared__ unsigned int live;
+    __shared__ unsigned long long esum;
+    if (threadIdx.x < 64) h[threadIdx.x] = 0;
+    if (threadIdx.x == 0) { live = 0; esum = 0; }
+    __syncthreads();
+    unsigned long long mysum = 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int b = ext_bin[i];
+        if (b) { atomicAdd(&h[b - 1], 1u); atomicAdd(&live, 1u); }
+        if (est) mysum += est[i];
+    }
+    for (int off = 32; off > 0; off >>= 1) mysum += __shfl_xor(mysum, off);
+    if ((threadIdx.x & 63) == 0 && mysum) atomicAdd(&esum, mysum);
+    __syncthreads();
+    if (threadIdx.x < 64) st->hist[threadIdx.x] = h[threadIdx.x];
+    if (threadIdx.x == 0) { st->live_tiles = live; st->est_sum = esum; }
 }
 
 // ---- work items: (tile, lane range) ---------------------------------------------------------------------
@@ -191,8 +210,8 @@ __device__ __forceinline__ uint32_t pack_item(int tile, int lane0, int lanes) { 
 // One wavefront per tile: count the records in the cells of the tile's region; if that exceeds the
 // threshold, halve the lane range and look at each half's own (smaller) region, down to single lanes.
 __global__ void __launch_bounds__(256) k_tile_plan(HpArrays hp, const uint32_t* __restrict__ cell_start, TileParams tp, uint32_t threshold,
-                                                   uint32_t* __restrict__ items, unsigned int* __restrict__ n_items,
-                                                   unsigned long long* __restrict__ est_sum)
+                                                   uint32_t* __restrict__ items, unsigned int* __restrict__ n_extra,
+                                                   uint32_t* __restrict__ est)
 {
     __shared__ uint32_t s_stack[4][16];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -203,11 +222,12 @@ __global__ void __launch_bounds__(256) k_tile_plan(HpArrays hp, const uint32_t* 
     const int p = slot < tp.n_pix ? tp.order[slot] : 0;
     bool live = slot < tp.n_pix;
     if (live) live = hp.valid[p] != 0;
-    if (__ballot(live) == 0) return;
+    if (__ballot(live) == 0) { if (lane == 0) { items[k] = 0xFFFFFFFFu; est[k] = 0; } return; }
     const double BIG = 1e300;
     const double x = live ? hp.pos[p] : 0.0, y = live ? hp.pos[P + p] : 0.0, z = live ? hp.pos[2 * P + p] : 0.0;
     const double rr = live ? sqrt(fmin(hp.r2[p], tp.gather_r2)) * (1.0 + 1e-9) + 1e-9 : 0.0;
     int sp = 0;
+    bool slot_used = false;  // items[k] is this tile's own slot; further pieces go behind n_owned
     if (lane == 0) s_stack[wv][0] = (0u << 8) | 64u;  // (first lane, lanes)
     sp = 1;
     bool first = true;
@@ -236,9 +256,13 @@ __global__ void __launch_bounds__(256) k_tile_plan(HpArrays hp, const uint32_t* 
         }
         for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
         sum = (unsigned int)__builtin_amdgcn_readfirstlane((int)sum);
-        if (first) { if (lane == 0) atomicAdd(est_sum, (unsigned long long)sum); first = false; }
+        if (first) { if (lane == 0) est[k] = sum; first = false; }
         if (sum <= threshold || len == 1) {
-            if (lane == 0) items[atomicAdd(n_items, 1u)] = pack_item(k, a, len);
+            if (lane == 0) {
+                if (!slot_used) items[k] = pack_item(k, a, len);
+                else items[tp.n_owned + atomicAdd(n_extra, 1u)] = pack_item(k, a, len);
+            }
+            slot_used = true;
         } else {
             if (lane == 0) { s_stack[wv][sp] = ((uint32_t)(a + len / 2) << 8) | (uint32_t)(len / 2); s_stack[wv][sp + 1] = ((uint32_t)a << 8) | (uint32_t)(len / 2); }
             sp += 2;
@@ -249,14 +273,15 @@ __global__ void __launch_bounds__(256) k_tile_plan(HpArrays hp, const uint32_t* 
 template <bool STAMPS>
 __global__ void __launch_bounds__(256) k_gather_tiles(HpArrays hp, DevScene sc, RecArrays rec, const uint32_t* __restrict__ cell_start,
                                                       TileParams tp, const uint32_t* __restrict__ items, const unsigned int* __restrict__ n_items,
-                                                      unsigned long long* __restrict__ counters)
+                                                      unsigned int item_base, unsigned long long* __restrict__ counters)
 {
     __shared__ unsigned long long s_key[4][64];
     __shared__ uint32_t s_rec[4][64];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const unsigned int item_i = blockIdx.x * 4 + wv;
-    if (item_i >= *n_items) return;
+    const unsigned int item_i = item_base + blockIdx.x * 4 + wv;
+    if (item_i >= (unsigned int)tp.n_owned + *n_items) return;
     const uint32_t item = items[item_i];
+    if (item == 0xFFFFFFFFu) return;  // a tile without live hitpoints
     const int k = (int)(item >> 12), lane0 = (int)((item >> 6) & 63u), lanes = (int)(item & 63u) + 1;
     const int slot = k * 64 + lane;
     const int P = hp.P;

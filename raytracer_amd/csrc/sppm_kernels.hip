@@ -574,8 +574,8 @@ struct sppm_ctx {
     int32_t *d_own_pix, *d_order; int n_own_pix;
     unsigned long long *d_hp_keys, *d_hp_keys_out, *d_hp_bb;
     void* d_sort_tmp; size_t sort_tmp_bytes;
-    uint32_t *d_est, *d_items; unsigned int* d_n_items; unsigned long long* d_est_sum;
-    double split_factor, est_per_photon;
+    uint32_t *d_est, *d_items; unsigned int* d_n_items; unsigned long long* d_est_sum; uint8_t* d_ext_bin; int est_valid;
+    double split_factor, est_per_photon; int64_t est_range; unsigned int extra_items_bound;
     int order_valid;
     sppm_sphere* d_spheres; int ns;
     Camera cam;
@@ -730,8 +730,8 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
         }
         c->sort_tmp_bytes = 0; c->d_sort_tmp = nullptr; c->order_valid = 0;
         TRY(dev_alloc(c, &c->d_est, (size_t)c->n_owned + 1)); TRY(dev_alloc(c, &c->d_items, (size_t)c->n_owned * 64 + 64, false));
-        TRY(dev_alloc(c, &c->d_n_items, 1)); TRY(dev_alloc(c, &c->d_est_sum, 1));
-        c->split_factor = 4.0; c->est_per_photon = 0.0;
+        TRY(dev_alloc(c, &c->d_n_items, 1)); TRY(dev_alloc(c, &c->d_est_sum, 1)); TRY(dev_alloc(c, &c->d_ext_bin, (size_t)c->n_owned + 1)); c->est_valid = 0;
+        c->split_factor = 4.0; c->est_per_photon = 0.0; c->est_range = 0; c->extra_items_bound = 8192;
         { const char* e = getenv("SPPM_SPLIT_FACTOR"); if (e && *e) c->split_factor = atof(e); }
         if (c->n_own_pix > 0) {
             if (rocprim::radix_sort_pairs(nullptr, c->sort_tmp_bytes, c->d_hp_keys, c->d_hp_keys_out, c->d_own_pix, c->d_order,
@@ -924,14 +924,14 @@ static int gather_tiles(sppm_ctx* c)
     if (!c->order_valid) return fail(SPPM_ERR_STATE, "sppm_gather: no eye pass has run on this context yet");
     tp.order = c->d_order; tp.n_pix = c->n_own_pix; tp.n_owned = c->n_owned;
     tp.tap_key = c->d_tap_key; tp.tap_pix = c->d_tap_pix; tp.tap_n = c->d_tap_n; tp.tap_cap = c->tap_cap;
-    // --- statistics of the tiles' regions
+    // --- statistics of the tiles' regions (and the mean record estimate of the previous batch's plan)
     TileStats hs;
-    memset(&hs, 0, sizeof hs);
-    hs.bb[0] = hs.bb[1] = hs.bb[2] = ~0ull;
-    HIPCHK(hipMemcpyAsync(c->d_stats, &hs, sizeof hs, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_tile_stats, dim3(nblk(c->n_owned, 4)), dim3(256), 0, st, c->hp, tp, c->d_stats);
+    unsigned long long bbq[6];
+    hipLaunchKernelGGL(k_tile_extent, dim3(nblk(c->n_owned, 4)), dim3(256), 0, st, c->hp, tp, c->d_ext_bin);
+    hipLaunchKernelGGL(k_tile_hist, dim3(1), dim3(1024), 0, st, c->d_ext_bin, c->est_valid ? c->d_est : (const uint32_t*)nullptr, c->n_owned, c->d_stats);
     unsigned long long cnt0[24];
     HIPCHK(hipMemcpyAsync(&hs, c->d_stats, sizeof hs, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(bbq, c->d_hp_bb, sizeof bbq, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(cnt0, c->d_counters, sizeof cnt0, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     if (hs.live_tiles == 0) return finish_batch(c);
@@ -940,7 +940,9 @@ static int gather_tiles(sppm_ctx* c)
     { unsigned int acc = 0; for (int e = 0; e < 64; e++) { acc += hs.hist[e]; if (2 * acc >= hs.live_tiles) { med = e; break; } } }
     double cell = std::ldexp(1.0, med - 32) * c->cell_factor;
     double lo[3], hi[3];
-    for (int k = 0; k < 3; k++) { lo[k] = undo_ord(hs.bb[k]); hi[k] = undo_ord(hs.bb[3 + k]); }
+    // grid box: the hitpoints' bounding box (made by the eye pass) grown by the largest search radius
+    const double rgrow = std::sqrt(c->cfg.gather_radius2) * (1.0 + 1e-9) + 1e-9;
+    for (int k = 0; k < 3; k++) { lo[k] = undo_ord(bbq[k]) - rgrow; hi[k] = undo_ord(bbq[3 + k]) + rgrow; }
     int64_t dims[3], ncells;
     for (;;) {
         ncells = 1;
@@ -967,32 +969,42 @@ static int gather_tiles(sppm_ctx* c)
     hipLaunchKernelGGL(k_grid_scatter, dim3(2048), dim3(256), 0, st, c->rec_u, c->rec_s, c->d_rec_count, c->d_rec_bucket, c->d_cursor);
     // --- work items: cut tiles whose region holds far more records than the average tile's.  The
     // threshold comes from the previous batch's mean (scaled by the photon count); the first batch is not cut.
-    HIPCHK(hipMemsetAsync(c->d_est_sum, 0, sizeof(unsigned long long), st));
     HIPCHK(hipMemsetAsync(c->d_n_items, 0, sizeof(unsigned int), st));
-    const double thr_d = c->est_per_photon > 0.0 ? std::max(256.0, c->est_per_photon * (double)range * c->split_factor) : 4.0e9;
+    if (c->est_valid && c->est_range > 0) c->est_per_photon = (double)hs.est_sum / (double)hs.live_tiles / (double)c->est_range;
+    const double mean_est = c->est_per_photon * (double)range;
+    const double thr_d = c->est_per_photon > 0.0 ? std::max(256.0, mean_est * c->split_factor) : 4.0e9;
     const uint32_t split_thr = (uint32_t)std::min(4.0e9, thr_d);
-    hipLaunchKernelGGL(k_tile_plan, dim3(nblk(c->n_owned, 4)), dim3(256), 0, st, c->hp, c->d_cell_start, tp, split_thr, c->d_items, c->d_n_items, c->d_est_sum);
-    unsigned long long est_sum = 0;
-    unsigned int n_items = 0;
-    HIPCHK(hipMemcpyAsync(&est_sum, c->d_est_sum, sizeof est_sum, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(&n_items, c->d_n_items, sizeof n_items, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    const double mean_est = (double)est_sum / (double)hs.live_tiles;
-    c->est_per_photon = mean_est / (double)range;
+    hipLaunchKernelGGL(k_tile_plan, dim3(nblk(c->n_owned, 4)), dim3(256), 0, st, c->hp, c->d_cell_start, tp, split_thr, c->d_items, c->d_n_items, c->d_est);
+    c->est_valid = 1; c->est_range = range;
+    // the gather grid must cover n_owned own slots + the extra pieces; their count is known only on the
+    // device, so launch for the worst case seen so far (waves beyond the count exit at once)
+    const unsigned int n_items = (unsigned int)c->n_owned + c->extra_items_bound;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     const bool dbg = getenv("SPPM_DEBUG") != nullptr;
     if (dbg) { HIPCHK(hipMemsetAsync(c->d_counters + 8, 0, 16 * sizeof(unsigned long long), st)); }
     if (c->timing || dbg) { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventRecord(e0, st)); }
     if (getenv("SPPM_STAMPS"))
-        hipLaunchKernelGGL(k_gather_tiles<true>, dim3(nblk(n_items, 4)), dim3(256), 0, st, c->hp, scene_of(c), c->rec_s, c->d_cell_start, tp, c->d_items, c->d_n_items, c->d_counters);
+        hipLaunchKernelGGL(k_gather_tiles<true>, dim3(nblk(n_items, 4)), dim3(256), 0, st, c->hp, scene_of(c), c->rec_s, c->d_cell_start, tp, c->d_items, c->d_n_items, 0u, c->d_counters);
     else
-        hipLaunchKernelGGL(k_gather_tiles<false>, dim3(nblk(n_items, 4)), dim3(256), 0, st, c->hp, scene_of(c), c->rec_s, c->d_cell_start, tp, c->d_items, c->d_n_items, c->d_counters);
+        hipLaunchKernelGGL(k_gather_tiles<false>, dim3(nblk(n_items, 4)), dim3(256), 0, st, c->hp, scene_of(c), c->rec_s, c->d_cell_start, tp, c->d_items, c->d_n_items, 0u, c->d_counters);
     if (c->timing || dbg) { HIPCHK(hipEventRecord(e1, st)); }
     HIPCHK(hipGetLastError());
     float dbg_ms = 0.f;
     if (dbg) { HIPCHK(hipEventSynchronize(e1)); HIPCHK(hipEventElapsedTime(&dbg_ms, e0, e1)); }
     if (c->timing) c->ev.push_back({e0, e1});
     else if (dbg) { hipEventDestroy(e0); hipEventDestroy(e1); }
+    {   // pieces beyond the launched worst case (rare): run them now, and remember the new bound
+        unsigned int extra = 0;
+        HIPCHK(hipMemcpyAsync(&extra, c->d_n_items, sizeof extra, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (extra > c->extra_items_bound) {
+            const unsigned int base = (unsigned int)c->n_owned + c->extra_items_bound;
+            hipLaunchKernelGGL(k_gather_tiles<false>, dim3(nblk(extra - c->extra_items_bound, 4)), dim3(256), 0, st, c->hp, scene_of(c), c->rec_s, c->d_cell_start, tp,
+                               c->d_items, c->d_n_items, base, c->d_counters);
+            HIPCHK(hipGetLastError());
+            c->extra_items_bound = extra + extra / 2;
+        }
+    }
     unsigned long long cnt1[24];
     HIPCHK(hipMemcpyAsync(cnt1, c->d_counters, sizeof cnt1, hipMemcpyDeviceToHost, st));
     rc = finish_batch(c);  // synchronises
