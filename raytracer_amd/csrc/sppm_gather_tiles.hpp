@@ -133,6 +133,7 @@ __global__ void k_bin_count(RecArrays rec, const unsigned long long* __restrict_
 {
     const int64_t n = min((int64_t)*rec_count, rec.cap);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        if (rec.key[i] == ~0ull) { rec_bucket[i] = 0xFFFFFFFFu; continue; }  // a hole left by the tracer's chunked slot reservation
         const int ix = grid_coord(rec.f[i], g.ox, g.inv_c, g.nx);
         const int iy = grid_coord(rec.f[rec.cap + i], g.oy, g.inv_c, g.ny);
         const int iz = grid_coord(rec.f[2 * rec.cap + i], g.oz, g.inv_c, g.nz);
@@ -197,6 +198,16 @@ __global__ void __launch_bounds__(1024) k_tile_hist(const uint8_t* __restrict__ 
     if (threadIdx.x == 0) { st->live_tiles = live; st->est_sum = esum; }
 }
 
+// records per cell summed over the slabs of the batch (what the plan's estimates read)
+__global__ void k_cell_totals(const uint32_t* __restrict__ cell_cnt, int ncells, int S, uint32_t* __restrict__ cell_tot)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncells) return;
+    uint32_t t = 0;
+    for (int s = 0; s < S; s++) t += cell_cnt[(size_t)s * ncells + c];
+    cell_tot[c] = t;
+}
+
 // ---- work items: (tile, lane range) ---------------------------------------------------------------------
 // Record density is very uneven (caustics, the gap between the light and the ceiling hold a few
 // percent of all records in a few square units).  A tile there has ~100x the average work, and a tile
@@ -209,7 +220,7 @@ __device__ __forceinline__ uint32_t pack_item(int tile, int lane0, int lanes) { 
 
 // One wavefront per tile: count the records in the cells of the tile's region; if that exceeds the
 // threshold, halve the lane range and look at each half's own (smaller) region, down to single lanes.
-__global__ void __launch_bounds__(256) k_tile_plan(HpArrays hp, const uint32_t* __restrict__ cell_start, TileParams tp, uint32_t threshold,
+__global__ void __launch_bounds__(256) k_tile_plan(HpArrays hp, const uint32_t* __restrict__ cell_tot, TileParams tp, uint32_t threshold,
                                                    uint32_t* __restrict__ items, unsigned int* __restrict__ n_extra,
                                                    uint32_t* __restrict__ est)
 {
@@ -248,11 +259,7 @@ __global__ void __launch_bounds__(256) k_tile_plan(HpArrays hp, const uint32_t* 
         unsigned int sum = 0;
         for (int q = lane; q < Ktot; q += 64) {
             const int ix = cx0 + q % kx, iy = cy0 + (q / kx) % ky, iz = cz0 + q / (kx * ky);
-            const uint32_t cell = (uint32_t)((iz * tp.g.ny + iy) * tp.g.nx + ix);
-            for (int s = 0; s < tp.g.S; s++) {
-                const uint32_t b = (uint32_t)s * (uint32_t)tp.g.ncells + cell;
-                sum += cell_start[b + 1] - cell_start[b];
-            }
+            sum += cell_tot[(iz * tp.g.ny + iy) * tp.g.nx + ix];
         }
         for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
         sum = (unsigned int)__builtin_amdgcn_readfirstlane((int)sum);

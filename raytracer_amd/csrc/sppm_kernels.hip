@@ -174,84 +174,146 @@ struct TraceParams {
 };
 struct RecArrays { uint64_t* key; double* f; int64_t cap; };  // f[9][cap]
 
-// One thread per photon: create_photon, src/sppm2.h:317-525, with the kd search + update replaced
-// by appending a photon-hit record (diffuse hit, depth > 0).
-__global__ void __launch_bounds__(256) k_photon_trace(DevScene sc, TraceParams tp, RecArrays rec, unsigned long long* __restrict__ rec_count,
-                                                      unsigned long long* __restrict__ counters, int32_t* __restrict__ err)
+// create_photon, src/sppm2.h:317-525, with the kd search + update replaced by appending a photon-hit
+// record (diffuse hit, depth > 0).  Photon paths have very different lengths (the longest of 64 is
+// ~3x the mean), so lanes are not bound to photons: a lane whose photon has ended takes the next
+// photon index of its wavefront's current block of 64 (blocks come from one global counter), emits it,
+// and all lanes then advance one bounce together.  Which lane traces which photon does not matter:
+// the stream is keyed by the photon index and records are ordered by key later.
+struct PhotonState { XorShift rng; d3 org, dir, flux; int depth; int64_t index; };
+struct Deposit { bool want; unsigned long long key; d3 pos, nrm, flux; };
+
+__device__ __forceinline__ void photon_emit(const DevScene& sc, const TraceParams& tp, int64_t i, PhotonState& ps)
 {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    ps.index = i;
+    ps.rng = make_stream(tp.seed_photon, (uint64_t)tp.pass * (uint64_t)tp.photons_per_pass + (uint64_t)i);
+    (void)ps.rng.next01(); (void)ps.rng.next01();  // two draws computed and discarded, src/sppm2.h:322-324
+    const double r1 = 2 * SPPM_PI * ps.rng.next01();
+    const double r2 = 1.0 - 2.0 * ps.rng.next01();
+    const double r3 = 1.0 - r2 * r2;
+    double sn, cs;
+    dm_sincos(r1, &sn, &cs);
+    const d3 lc = ld3(sc.sp[0].position);
+    const d3 source_pos = lc + mk(sqrt(r3) * cs, sqrt(r3) * sn, r2) * (sc.sp[0].radius + SPPM_EPS);
+    const d3 w = normalize(source_pos - lc);
+    d3 u, v;
+    basis(w, u, v);
+    ps.org = source_pos;
+    ps.dir = cosine_sampling(w, u, v, ps.rng);
+    ps.flux = ld3(sc.sp[0].emission) * 4.0 * tp.flux_scale;
+    ps.depth = -1;
+}
+
+// one iteration of the while loop of create_photon; returns false when the path ends
+__device__ __forceinline__ bool photon_bounce(const DevScene& sc, PhotonState& ps, Deposit& dep, int32_t* __restrict__ err, uint32_t& rays)
+{
+    if (max3(ps.flux) <= 0.0) return false;
+    Hit is;
+    rays++;
+    if (!intersect_scene(sc.sp, sc.ns, ps.org, ps.dir, is)) return false;
+    const sppm_sphere* obj = &sc.sp[is.object_id];
+    const d3 color = ld3(obj->color);
+    const int type = obj->reflection_type;
+    const bool flip = !(dot(is.normal, ps.dir) < 0.0);
+    const d3 on = flip ? is.normal * -1.0 : is.normal;
+    ps.depth++;
+    if (type == SPPM_DIFFUSE) {
+        if (ps.depth > 0) {
+            if (ps.depth > 32767) { err[1] = 1; return false; }
+            // the record is stored by the caller, where the whole wavefront has reconverged
+            dep.want = true;
+            dep.key = ((uint64_t)ps.index << 16) | ((uint64_t)ps.depth << 1) | (flip ? 1ull : 0ull);
+            dep.pos = is.position; dep.nrm = is.normal; dep.flux = ps.flux;
+        }
+        const double prob = (color.x + color.y + color.z) / 3;
+        if (!(prob > ps.rng.next01())) return false;
+        d3 du, dv;
+        basis(on, du, dv);
+        ps.dir = cosine_sampling(on, du, dv, ps.rng);
+        ps.org = is.position;
+        ps.flux = had(ps.flux, color) / prob;
+    } else if (type == SPPM_SPECULAR) {
+        ps.dir = reflect_dir(ps.dir, is.normal);
+        ps.org = is.position;
+        ps.flux = had(ps.flux, color);
+    } else {
+        const d3 rdir = reflect_dir(ps.dir, is.normal);
+        bool into; double nnt, Re; d3 tdir;
+        ps.org = is.position;
+        if (!glass(ps.dir, is.normal, on, false, into, nnt, tdir, Re)) ps.dir = rdir;
+        else ps.dir = (ps.rng.next01() < Re) ? rdir : tdir;
+        ps.flux = had(ps.flux, color);
+    }
+    return true;
+}
+
+#define TRACE_GRAB 64
+#define REC_CHUNK 128  // record slots a wavefront reserves at a time (one atomic per chunk instead of one per record)
+#define REC_INVALID (~0ull)
+__global__ void __launch_bounds__(256) k_photon_trace(DevScene sc, TraceParams tp, RecArrays rec, unsigned long long* __restrict__ rec_count,
+                                                      unsigned long long* __restrict__ next_block, unsigned long long* __restrict__ counters,
+                                                      int32_t* __restrict__ err)
+{
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     uint32_t rays = 0;
-    if (t < tp.count) {
-        const int64_t i = tp.first + t;
-        XorShift rng = make_stream(tp.seed_photon, (uint64_t)tp.pass * (uint64_t)tp.photons_per_pass + (uint64_t)i);
-        (void)rng.next01(); (void)rng.next01();  // two draws computed and discarded, src/sppm2.h:322-324
-        const double r1 = 2 * SPPM_PI * rng.next01();
-        const double r2 = 1.0 - 2.0 * rng.next01();
-        const double r3 = 1.0 - r2 * r2;
-        double sn, cs;
-        dm_sincos(r1, &sn, &cs);
-        const d3 lc = ld3(sc.sp[0].position);
-        const d3 source_pos = lc + mk(sqrt(r3) * cs, sqrt(r3) * sn, r2) * (sc.sp[0].radius + SPPM_EPS);
-        const d3 w = normalize(source_pos - lc);
-        d3 u, v;
-        basis(w, u, v);
-        d3 org = source_pos;
-        d3 dir = cosine_sampling(w, u, v, rng);
-        d3 flux = ld3(sc.sp[0].emission) * 4.0 * tp.flux_scale;
-        int depth = -1;
-        for (;;) {
-            if (max3(flux) <= 0.0) break;
-            Hit is;
-            rays++;
-            if (!intersect_scene(sc.sp, sc.ns, org, dir, is)) break;
-            const sppm_sphere* obj = &sc.sp[is.object_id];
-            const d3 color = ld3(obj->color);
-            const int type = obj->reflection_type;
-            const bool flip = !(dot(is.normal, dir) < 0.0);
-            const d3 on = flip ? is.normal * -1.0 : is.normal;
-            depth++;
-            if (type == SPPM_DIFFUSE) {
-                if (depth > 0) {
-                    if (depth > 32767) { err[1] = 1; break; }
-                    const unsigned long long slot = atomicAdd(rec_count, 1ull);
-                    if ((int64_t)slot < rec.cap) {
-                        rec.key[slot] = ((uint64_t)i << 16) | ((uint64_t)depth << 1) | (flip ? 1ull : 0ull);
-                        double* f = rec.f + slot;
-                        const int64_t c = rec.cap;
-                        f[0] = is.position.x; f[c] = is.position.y; f[2 * c] = is.position.z;
-                        f[3 * c] = is.normal.x; f[4 * c] = is.normal.y; f[5 * c] = is.normal.z;
-                        f[6 * c] = flux.x; f[7 * c] = flux.y; f[8 * c] = flux.z;
-                    } else
-                        err[0] = 1;
+    PhotonState ps;
+    ps.depth = 0; ps.index = 0; ps.org = mk(0, 0, 0); ps.dir = mk(0, 0, 1); ps.flux = mk(0, 0, 0); ps.rng.seed(1u);
+    bool active = false, exhausted = false;
+    int64_t blk_lo = 0, blk_hi = 0;  // wave-uniform: the unassigned rest of this wave's current block
+    int64_t chunk_lo = 0, chunk_hi = 0;  // wave-uniform: the unused rest of this wave's reserved record slots
+    bool rec_full = false;
+    for (;;) {
+        const unsigned long long need = __ballot(!active);
+        if (need != 0 && !exhausted) {
+            if (blk_lo >= blk_hi) {
+                unsigned long long base = 0;
+                if (lane == 0) base = atomicAdd(next_block, (unsigned long long)TRACE_GRAB);
+                base = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) |
+                       (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)base);
+                blk_lo = (int64_t)base;
+                blk_hi = min((int64_t)base + TRACE_GRAB, tp.count);
+                if (blk_lo >= tp.count) { exhausted = true; blk_lo = blk_hi = 0; }
+            }
+            const int64_t idx = blk_lo + __popcll(need & lt_mask);
+            if (!active && idx < blk_hi) { photon_emit(sc, tp, tp.first + idx, ps); active = true; }
+            blk_lo = min(blk_hi, blk_lo + (int64_t)__popcll(need));
+        }
+        if (__ballot(active) == 0) { if (exhausted) break; else continue; }
+        Deposit dep;
+        dep.want = false;
+        if (active) active = photon_bounce(sc, ps, dep, err, rays);
+        // store the records of this step: slots come from the wave's chunk, a new chunk costs one atomic
+        const unsigned long long dm = __ballot(dep.want);
+        if (dm != 0 && !rec_full) {
+            const int cnt = __popcll(dm);
+            if (chunk_lo + cnt > chunk_hi) {
+                if (lane < chunk_hi - chunk_lo) rec.key[chunk_lo + lane] = REC_INVALID;  // fewer than 64 left: mark them as holes
+                unsigned long long base = 0;
+                if (lane == 0) base = atomicAdd(rec_count, (unsigned long long)REC_CHUNK);
+                base = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) |
+                       (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)base);
+                chunk_lo = (int64_t)base;
+                chunk_hi = (int64_t)base + REC_CHUNK;
+                if (chunk_hi > rec.cap) { rec_full = true; chunk_lo = chunk_hi = 0; if (lane == 0) err[0] = 1; }
+            }
+            if (!rec_full) {
+                if (dep.want) {
+                    const int64_t slot = chunk_lo + __popcll(dm & lt_mask);
+                    rec.key[slot] = dep.key;
+                    double* f = rec.f + slot;
+                    const int64_t c = rec.cap;
+                    f[0] = dep.pos.x; f[c] = dep.pos.y; f[2 * c] = dep.pos.z;
+                    f[3 * c] = dep.nrm.x; f[4 * c] = dep.nrm.y; f[5 * c] = dep.nrm.z;
+                    f[6 * c] = dep.flux.x; f[7 * c] = dep.flux.y; f[8 * c] = dep.flux.z;
                 }
-                const double prob = (color.x + color.y + color.z) / 3;
-                if (prob > rng.next01()) {
-                    d3 du, dv;
-                    basis(on, du, dv);
-                    dir = cosine_sampling(on, du, dv, rng);
-                    org = is.position;
-                    flux = had(flux, color) / prob;
-                } else
-                    break;
-            } else if (type == SPPM_SPECULAR) {
-                dir = reflect_dir(dir, is.normal);
-                org = is.position;
-                flux = had(flux, color);
-            } else {
-                const d3 rdir = reflect_dir(dir, is.normal);
-                bool into; double nnt, Re; d3 tdir;
-                org = is.position;
-                if (!glass(dir, is.normal, on, false, into, nnt, tdir, Re)) {
-                    dir = rdir;
-                } else {
-                    dir = (rng.next01() < Re) ? rdir : tdir;
-                }
-                flux = had(flux, color);
+                chunk_lo += cnt;
             }
         }
     }
+    for (int64_t j = chunk_lo + lane; j < chunk_hi; j += 64) rec.key[j] = REC_INVALID;
     for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off);
-    if ((threadIdx.x & 63) == 0 && rays) atomicAdd(&counters[0], (unsigned long long)rays);
+    if (lane == 0 && rays) atomicAdd(&counters[0], (unsigned long long)rays);
 }
 
 // ---- hash grid over the records of a batch ----------------------------------------------------------
@@ -268,6 +330,7 @@ __global__ void k_grid_count(RecArrays rec, const unsigned long long* __restrict
 {
     const int64_t n = min((int64_t)*rec_count, rec.cap);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        if (rec.key[i] == REC_INVALID) { rec_bucket[i] = 0xFFFFFFFFu; continue; }  // a hole left by the tracer's chunked slot reservation
         const uint32_t b = cell_hash(cell_coord(rec.f[i], g.inv_cell), cell_coord(rec.f[rec.cap + i], g.inv_cell),
                                      cell_coord(rec.f[2 * rec.cap + i], g.inv_cell), g.mask);
         rec_bucket[i] = b;
@@ -340,6 +403,7 @@ __global__ void k_grid_scatter(RecArrays src, RecArrays dst, const unsigned long
 {
     const int64_t n = min((int64_t)*rec_count, src.cap);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        if (rec_bucket[i] == 0xFFFFFFFFu) continue;
         const uint32_t p = atomicAdd(&cursor[rec_bucket[i]], 1u);
         dst.key[p] = src.key[i];
 #pragma unroll
@@ -574,7 +638,7 @@ struct sppm_ctx {
     int32_t *d_own_pix, *d_order; int n_own_pix;
     unsigned long long *d_hp_keys, *d_hp_keys_out, *d_hp_bb;
     void* d_sort_tmp; size_t sort_tmp_bytes;
-    uint32_t *d_est, *d_items; unsigned int* d_n_items; unsigned long long* d_est_sum; uint8_t* d_ext_bin; int est_valid;
+    uint32_t *d_cell_tot, *d_est, *d_items; unsigned int* d_n_items; unsigned long long* d_est_sum; uint8_t* d_ext_bin; int est_valid;
     double split_factor, est_per_photon; int64_t est_range; unsigned int extra_items_bound;
     int order_valid;
     sppm_sphere* d_spheres; int ns;
@@ -586,6 +650,7 @@ struct sppm_ctx {
     unsigned long long* d_rec_count;
     unsigned long long* d_counters;  // 8: [0] rays [3] candidates [4] updates [5] selected [6] rounds [7] live tile launches
     unsigned long long* d_r2max;
+    unsigned long long* d_trace_next;
     int32_t* d_err;                  // 4
     uint32_t *d_cell_cnt, *d_cell_start, *d_cursor, *d_block_sum, *d_total, *d_rec_bucket;
     uint32_t n_buckets;
@@ -711,7 +776,7 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
     if (c->gather_mode) nb = (uint32_t)((c->table_cap + SCAN_BLOCK) / SCAN_BLOCK * SCAN_BLOCK);
     TRY(dev_alloc(c, &c->d_cell_cnt, (size_t)nb)); TRY(dev_alloc(c, &c->d_cell_start, (size_t)nb + 1)); TRY(dev_alloc(c, &c->d_cursor, (size_t)nb));
     TRY(dev_alloc(c, &c->d_block_sum, (size_t)nb / SCAN_BLOCK + 1)); TRY(dev_alloc(c, &c->d_total, 1));
-    TRY(dev_alloc(c, &c->d_rec_count, 1)); TRY(dev_alloc(c, &c->d_counters, 24)); TRY(dev_alloc(c, &c->d_r2max, 1)); TRY(dev_alloc(c, &c->d_err, 4));
+    TRY(dev_alloc(c, &c->d_rec_count, 1)); TRY(dev_alloc(c, &c->d_counters, 24)); TRY(dev_alloc(c, &c->d_r2max, 1)); TRY(dev_alloc(c, &c->d_trace_next, 1)); TRY(dev_alloc(c, &c->d_err, 4));
     TRY(dev_alloc(c, &c->d_stats, 1));
     {   // the image indices this rank owns (8x8 screen tiles dealt round-robin), in index order
         std::vector<int32_t> own;
@@ -730,7 +795,7 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
         }
         c->sort_tmp_bytes = 0; c->d_sort_tmp = nullptr; c->order_valid = 0;
         TRY(dev_alloc(c, &c->d_est, (size_t)c->n_owned + 1)); TRY(dev_alloc(c, &c->d_items, (size_t)c->n_owned * 64 + 64, false));
-        TRY(dev_alloc(c, &c->d_n_items, 1)); TRY(dev_alloc(c, &c->d_est_sum, 1)); TRY(dev_alloc(c, &c->d_ext_bin, (size_t)c->n_owned + 1)); c->est_valid = 0;
+        TRY(dev_alloc(c, &c->d_cell_tot, (size_t)c->table_cap / 4 + 1)); TRY(dev_alloc(c, &c->d_n_items, 1)); TRY(dev_alloc(c, &c->d_est_sum, 1)); TRY(dev_alloc(c, &c->d_ext_bin, (size_t)c->n_owned + 1)); c->est_valid = 0;
         c->split_factor = 4.0; c->est_per_photon = 0.0; c->est_range = 0; c->extra_items_bound = 8192;
         { const char* e = getenv("SPPM_SPLIT_FACTOR"); if (e && *e) c->split_factor = atof(e); }
         if (c->n_own_pix > 0) {
@@ -810,7 +875,10 @@ extern "C" int sppm_trace(sppm_ctx* c, int32_t pass, int64_t first, int64_t coun
     TraceParams tp;
     tp.pass = pass; tp.first = first; tp.count = count;
     tp.photons_per_pass = c->cfg.photons_per_pass; tp.seed_photon = c->cfg.seed_photon; tp.flux_scale = c->flux_scale; tp.rec_cap = c->rec_u.cap;
-    hipLaunchKernelGGL(k_photon_trace, dim3(nblk(count, 256)), dim3(256), 0, c->stream, scene_of(c), tp, c->rec_u, c->d_rec_count, c->d_counters, c->d_err);
+    // persistent waves: enough to fill the chip (4 waves per SIMD), never more than the photons need
+    HIPCHK(hipMemsetAsync(c->d_trace_next, 0, sizeof(unsigned long long), c->stream));
+    const int trace_blocks = (int)std::min<int64_t>(nblk(count, 256), 256 * 4);
+    hipLaunchKernelGGL(k_photon_trace, dim3(trace_blocks), dim3(256), 0, c->stream, scene_of(c), tp, c->rec_u, c->d_rec_count, c->d_trace_next, c->d_counters, c->d_err);
     HIPCHK(hipGetLastError());
     c->photons_traced += (uint64_t)count;
     if (c->rec_end == c->rec_first) { c->rec_first = first; c->rec_end = first + count; }
@@ -862,7 +930,11 @@ static int finish_batch(sppm_ctx* c)
     HIPCHK(hipMemcpyAsync(&cnt, c->d_rec_count, sizeof cnt, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     if ((int64_t)cnt > c->rec_u.cap) return fail(SPPM_ERR_OVERFLOW, "record buffer overflow: raise SPPM_RECORD_CAP or lower SPPM_BATCH_PHOTONS");
-    c->records_total += cnt;
+    if (cnt > 0) {  // slots include the holes of the tracer's chunked reservation: the scan total counts the records
+        uint32_t valid = 0;
+        HIPCHK(hipMemcpy(&valid, c->d_total, sizeof valid, hipMemcpyDeviceToHost));
+        c->records_total += valid;
+    }
     c->gather_batches++;
     c->photons_applied += (uint64_t)(c->rec_end - c->rec_first);
     c->rec_first = c->rec_end = 0;
@@ -974,7 +1046,8 @@ static int gather_tiles(sppm_ctx* c)
     const double mean_est = c->est_per_photon * (double)range;
     const double thr_d = c->est_per_photon > 0.0 ? std::max(256.0, mean_est * c->split_factor) : 4.0e9;
     const uint32_t split_thr = (uint32_t)std::min(4.0e9, thr_d);
-    hipLaunchKernelGGL(k_tile_plan, dim3(nblk(c->n_owned, 4)), dim3(256), 0, st, c->hp, c->d_cell_start, tp, split_thr, c->d_items, c->d_n_items, c->d_est);
+    hipLaunchKernelGGL(k_cell_totals, dim3(nblk(g.ncells, 256)), dim3(256), 0, st, c->d_cell_cnt, g.ncells, g.S, c->d_cell_tot);
+    hipLaunchKernelGGL(k_tile_plan, dim3(nblk(c->n_owned, 4)), dim3(256), 0, st, c->hp, c->d_cell_tot, tp, split_thr, c->d_items, c->d_n_items, c->d_est);
     c->est_valid = 1; c->est_range = range;
     // the gather grid must cover n_owned own slots + the extra pieces; their count is known only on the
     // device, so launch for the worst case seen so far (waves beyond the count exit at once)
@@ -1224,16 +1297,16 @@ extern "C" int sppm_download_records(sppm_ctx* c, uint64_t* h_key, double* h_f, 
     int64_t cnt = 0;
     int rc = sppm_records(c, nullptr, nullptr, &cnt, nullptr);
     if (rc) return rc;
-    *n = cnt;
-    if (!h_key && !h_f) return SPPM_OK;
     std::vector<uint64_t> key((size_t)cnt);
     std::vector<double> f(9 * (size_t)cnt);
     HIPCHK(hipMemcpy(key.data(), c->rec_u.key, (size_t)cnt * 8, hipMemcpyDeviceToHost));
     for (int k = 0; k < 9; k++) HIPCHK(hipMemcpy(f.data() + (size_t)k * cnt, c->rec_u.f + (size_t)k * c->rec_u.cap, (size_t)cnt * 8, hipMemcpyDeviceToHost));
-    std::vector<int64_t> order((size_t)cnt);
-    for (int64_t i = 0; i < cnt; i++) order[i] = i;
+    std::vector<int64_t> order;
+    for (int64_t i = 0; i < cnt; i++) if (key[i] != REC_INVALID) order.push_back(i);
     std::sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return key[a] < key[b]; });
-    for (int64_t i = 0; i < cnt; i++) {
+    *n = (int64_t)order.size();
+    if (!h_key && !h_f) return SPPM_OK;
+    for (int64_t i = 0; i < (int64_t)order.size(); i++) {
         if (h_key) h_key[i] = key[order[i]];
         if (h_f) for (int k = 0; k < 9; k++) h_f[9 * i + k] = f[(size_t)k * cnt + order[i]];
     }
