@@ -651,6 +651,14 @@ struct sppm_ctx {
     unsigned long long* d_counters;  // 8: [0] rays [3] candidates [4] updates [5] selected [6] rounds [7] live tile launches
     unsigned long long* d_r2max;
     unsigned long long* d_trace_next;
+    // double-buffered record buffers: the tracer fills one on its own stream while the gather consumes
+    // the other.  rec_u / d_rec_count / d_trace_next above always alias buffer `cur`.
+    RecArrays rec_buf[2]; unsigned long long* d_rec_count_buf[2]; unsigned long long* d_trace_next_buf[2];
+    int cur;
+    hipStream_t trace_stream;
+    hipEvent_t ev_traced[2], ev_free[2];
+    struct { int valid, buf, pass; int64_t first, count; } pre;  // a batch traced ahead of its photon_pass call
+    int prefetch;
     int32_t* d_err;                  // 4
     uint32_t *d_cell_cnt, *d_cell_start, *d_cursor, *d_block_sum, *d_total, *d_rec_bucket;
     uint32_t n_buckets;
@@ -730,6 +738,7 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
     c->rec_first = c->rec_end = 0;
     c->photons_applied = 0;
     c->ns = n_spheres;
+    c->trace_stream = nullptr; for (int b = 0; b < 2; b++) { c->ev_traced[b] = nullptr; c->ev_free[b] = nullptr; }
     c->tap_cap = 0; c->d_tap_key = nullptr; c->d_tap_pix = nullptr; c->d_tap_n = nullptr;
     c->timing = 0; c->gather_ns = c->gather_launches = c->gather_batches = 0; c->photons_traced = c->records_total = 0;
     int rc = 0;
@@ -767,7 +776,19 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
     if (c->batch_photons < 1024) c->batch_photons = 1024;
     const int64_t cap = env_i64("SPPM_RECORD_CAP", c->batch_photons * (c->gather_mode ? 4 : 8));
     c->rec_u.cap = c->rec_s.cap = cap;
-    TRY(dev_alloc(c, &c->rec_u.key, (size_t)cap, false)); TRY(dev_alloc(c, &c->rec_u.f, 9 * (size_t)cap, false));
+    for (int b = 0; b < 2; b++) {
+        c->rec_buf[b].cap = cap;
+        TRY(dev_alloc(c, &c->rec_buf[b].key, (size_t)cap, false)); TRY(dev_alloc(c, &c->rec_buf[b].f, 9 * (size_t)cap, false));
+        TRY(dev_alloc(c, &c->d_rec_count_buf[b], 1)); TRY(dev_alloc(c, &c->d_trace_next_buf[b], 1));
+    }
+    c->cur = 0; c->rec_u = c->rec_buf[0]; c->d_rec_count = c->d_rec_count_buf[0]; c->d_trace_next = c->d_trace_next_buf[0];
+    c->pre.valid = 0;
+    c->prefetch = (int)env_i64("SPPM_PREFETCH", 1);
+    if (hipStreamCreateWithFlags(&c->trace_stream, hipStreamNonBlocking) != hipSuccess) { sppm_destroy(c); return fail(SPPM_ERR_HIP, "creating the trace stream failed"); }
+    for (int b = 0; b < 2; b++)
+        if (hipEventCreateWithFlags(&c->ev_traced[b], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_free[b], hipEventDisableTiming) != hipSuccess) {
+            sppm_destroy(c); return fail(SPPM_ERR_HIP, "creating events failed");
+        }
     TRY(dev_alloc(c, &c->rec_s.key, (size_t)cap, false)); TRY(dev_alloc(c, &c->rec_s.f, 9 * (size_t)cap, false));
     TRY(dev_alloc(c, &c->d_rec_bucket, (size_t)cap, false));
     uint32_t nb = 1024;
@@ -776,7 +797,7 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
     if (c->gather_mode) nb = (uint32_t)((c->table_cap + SCAN_BLOCK) / SCAN_BLOCK * SCAN_BLOCK);
     TRY(dev_alloc(c, &c->d_cell_cnt, (size_t)nb)); TRY(dev_alloc(c, &c->d_cell_start, (size_t)nb + 1)); TRY(dev_alloc(c, &c->d_cursor, (size_t)nb));
     TRY(dev_alloc(c, &c->d_block_sum, (size_t)nb / SCAN_BLOCK + 1)); TRY(dev_alloc(c, &c->d_total, 1));
-    TRY(dev_alloc(c, &c->d_rec_count, 1)); TRY(dev_alloc(c, &c->d_counters, 24)); TRY(dev_alloc(c, &c->d_r2max, 1)); TRY(dev_alloc(c, &c->d_trace_next, 1)); TRY(dev_alloc(c, &c->d_err, 4));
+    TRY(dev_alloc(c, &c->d_counters, 24)); TRY(dev_alloc(c, &c->d_r2max, 1)); TRY(dev_alloc(c, &c->d_err, 4));
     TRY(dev_alloc(c, &c->d_stats, 1));
     {   // the image indices this rank owns (8x8 screen tiles dealt round-robin), in index order
         std::vector<int32_t> own;
@@ -817,7 +838,10 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
 extern "C" int sppm_destroy(sppm_ctx* c)
 {
     if (!c) return SPPM_OK;
+    if (c->trace_stream) hipStreamSynchronize(c->trace_stream);
     hipStreamSynchronize(c->stream);
+    for (int b = 0; b < 2; b++) { if (c->ev_traced[b]) hipEventDestroy(c->ev_traced[b]); if (c->ev_free[b]) hipEventDestroy(c->ev_free[b]); }
+    if (c->trace_stream) hipStreamDestroy(c->trace_stream);
     for (auto& e : c->ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (void* p : c->allocs) hipFree(p);
     delete c;
@@ -866,21 +890,35 @@ extern "C" int sppm_eye_pass(sppm_ctx* c, int32_t pass)
     return SPPM_OK;
 }
 
+static void set_cur(sppm_ctx* c, int b)
+{
+    c->cur = b; c->rec_u = c->rec_buf[b]; c->d_rec_count = c->d_rec_count_buf[b]; c->d_trace_next = c->d_trace_next_buf[b];
+}
+
+// launch the tracer for photons [first, first+count) of `pass` into record buffer b on stream st
+static int trace_into(sppm_ctx* c, int b, int32_t pass, int64_t first, int64_t count, hipStream_t st)
+{
+    TraceParams tp;
+    tp.pass = pass; tp.first = first; tp.count = count;
+    tp.photons_per_pass = c->cfg.photons_per_pass; tp.seed_photon = c->cfg.seed_photon; tp.flux_scale = c->flux_scale; tp.rec_cap = c->rec_buf[b].cap;
+    // persistent waves: enough to fill the chip (4 waves per SIMD), never more than the photons need
+    HIPCHK(hipMemsetAsync(c->d_trace_next_buf[b], 0, sizeof(unsigned long long), st));
+    const int trace_blocks = (int)std::min<int64_t>(nblk(count, 256), 256 * 4);
+    hipLaunchKernelGGL(k_photon_trace, dim3(trace_blocks), dim3(256), 0, st, scene_of(c), tp, c->rec_buf[b], c->d_rec_count_buf[b], c->d_trace_next_buf[b], c->d_counters, c->d_err);
+    HIPCHK(hipGetLastError());
+    c->photons_traced += (uint64_t)count;
+    return 0;
+}
+
 extern "C" int sppm_trace(sppm_ctx* c, int32_t pass, int64_t first, int64_t count)
 {
     if (!c || pass < 0 || first < 0 || count < 0) return fail(SPPM_ERR_INVALID, "sppm_trace: bad argument");
     if (c->cfg.photons_per_pass > 0 && first + count > c->cfg.photons_per_pass)
         return fail(SPPM_ERR_INVALID, "sppm_trace: photon range exceeds photons_per_pass");
     if (count == 0) return SPPM_OK;
-    TraceParams tp;
-    tp.pass = pass; tp.first = first; tp.count = count;
-    tp.photons_per_pass = c->cfg.photons_per_pass; tp.seed_photon = c->cfg.seed_photon; tp.flux_scale = c->flux_scale; tp.rec_cap = c->rec_u.cap;
-    // persistent waves: enough to fill the chip (4 waves per SIMD), never more than the photons need
-    HIPCHK(hipMemsetAsync(c->d_trace_next, 0, sizeof(unsigned long long), c->stream));
-    const int trace_blocks = (int)std::min<int64_t>(nblk(count, 256), 256 * 4);
-    hipLaunchKernelGGL(k_photon_trace, dim3(trace_blocks), dim3(256), 0, c->stream, scene_of(c), tp, c->rec_u, c->d_rec_count, c->d_trace_next, c->d_counters, c->d_err);
-    HIPCHK(hipGetLastError());
-    c->photons_traced += (uint64_t)count;
+    if (c->pre.valid && c->pre.buf == c->cur) set_cur(c, 1 - c->cur);  // keep away from a batch traced ahead
+    int rc = trace_into(c, c->cur, pass, first, count, c->stream);
+    if (rc) return rc;
     if (c->rec_end == c->rec_first) { c->rec_first = first; c->rec_end = first + count; }
     else { c->rec_first = std::min(c->rec_first, first); c->rec_end = std::max(c->rec_end, first + count); }
     return SPPM_OK;
@@ -1128,20 +1166,78 @@ extern "C" int sppm_gather(sppm_ctx* c)
     return c->gather_mode ? gather_tiles(c) : gather_simple(c);
 }
 
+static int64_t batch_size(const sppm_ctx* c, uint64_t applied)
+{
+    // Batches grow with the photons already applied: the radii shrink like N^-0.43, so a batch about
+    // half as long as the history changes them little while it runs.
+    int64_t n = c->batch_photons;
+    if (c->gather_mode) n = std::min<int64_t>(n, std::max<int64_t>(32768, (int64_t)(applied / 2)));
+    return n;
+}
+
+// drop a batch that was traced ahead but is not the one now asked for
+static int discard_prefetch(sppm_ctx* c)
+{
+    if (!c->pre.valid) return 0;
+    const int b = c->pre.buf;
+    HIPCHK(hipStreamSynchronize(c->trace_stream));
+    HIPCHK(hipMemsetAsync(c->d_rec_count_buf[b], 0, sizeof(unsigned long long), c->stream));
+    HIPCHK(hipEventRecord(c->ev_free[b], c->stream));
+    c->photons_traced -= (uint64_t)c->pre.count;
+    c->pre.valid = 0;
+    return 0;
+}
+
+// Photon pass in batches.  While the gather of batch k runs on the context's stream, the tracer
+// already fills the other record buffer with batch k+1 on its own stream -- across the end of the pass
+// too: photon paths do not depend on hitpoints, so the first batch of the NEXT pass is traced ahead on
+// the assumption that the caller will ask for the same photon range again (dropped if it does not).
+// The tracer's long tail (a few photons bounce hundreds of times inside the glass sphere) hides
+// behind the gather this way.
 extern "C" int sppm_photon_pass(sppm_ctx* c, int32_t pass, int64_t first, int64_t count)
 {
     if (!c || pass < 0 || first < 0 || count < 0) return fail(SPPM_ERR_INVALID, "sppm_photon_pass: bad argument");
-    for (int64_t done = 0; done < count;) {
-        // Batches grow with the photons already applied: the radii shrink like N^-0.43, so a batch
-        // about half as long as the history changes them little while it runs.
-        int64_t n = c->batch_photons;
-        if (c->gather_mode) n = std::min<int64_t>(n, std::max<int64_t>(32768, (int64_t)(c->photons_applied / 2)));
-        n = std::min(n, count - done);
-        int rc = sppm_trace(c, pass, first + done, n);
+    if (c->cfg.photons_per_pass > 0 && first + count > c->cfg.photons_per_pass)
+        return fail(SPPM_ERR_INVALID, "sppm_photon_pass: photon range exceeds photons_per_pass");
+    if (count == 0) return SPPM_OK;
+    if (c->rec_end != c->rec_first) return fail(SPPM_ERR_STATE, "sppm_photon_pass: records of an earlier sppm_trace are still waiting for sppm_gather");
+    int rc;
+    int64_t n = std::min(batch_size(c, c->photons_applied), count);
+    int b;
+    if (c->pre.valid && c->pre.pass == pass && c->pre.first == first && c->pre.count == n) {
+        b = c->pre.buf;
+        c->pre.valid = 0;
+    } else {
+        rc = discard_prefetch(c);
         if (rc) return rc;
+        b = c->cur;
+        HIPCHK(hipStreamWaitEvent(c->trace_stream, c->ev_free[b], 0));
+        rc = trace_into(c, b, pass, first, n, c->trace_stream);
+        if (rc) return rc;
+        HIPCHK(hipEventRecord(c->ev_traced[b], c->trace_stream));
+    }
+    for (int64_t done = 0; done < count;) {
+        // trace ahead into the other buffer
+        const int nb = 1 - b;
+        int64_t nn = 0; int npass = pass; int64_t nfirst = first + done + n;
+        if (done + n < count) nn = std::min(batch_size(c, c->photons_applied + (uint64_t)n), count - done - n);
+        else if (c->prefetch) { npass = pass + 1; nfirst = first; nn = std::min(batch_size(c, c->photons_applied + (uint64_t)n), count); }
+        if (nn > 0) {
+            HIPCHK(hipStreamWaitEvent(c->trace_stream, c->ev_free[nb], 0));
+            rc = trace_into(c, nb, npass, nfirst, nn, c->trace_stream);
+            if (rc) return rc;
+            HIPCHK(hipEventRecord(c->ev_traced[nb], c->trace_stream));
+        }
+        // gather batch b
+        HIPCHK(hipStreamWaitEvent(c->stream, c->ev_traced[b], 0));
+        set_cur(c, b);
+        c->rec_first = first + done; c->rec_end = first + done + n;
         rc = sppm_gather(c);
         if (rc) return rc;
+        HIPCHK(hipEventRecord(c->ev_free[b], c->stream));
         done += n;
+        if (nn > 0 && npass != pass) { c->pre.valid = 1; c->pre.buf = nb; c->pre.pass = npass; c->pre.first = nfirst; c->pre.count = nn; }
+        b = nb; n = nn;
     }
     return SPPM_OK;
 }
@@ -1237,6 +1333,7 @@ extern "C" int sppm_check(sppm_ctx* c)
 {
     if (!c) return fail(SPPM_ERR_INVALID, "sppm_check: null context");
     int32_t err[4] = {0, 0, 0, 0};
+    HIPCHK(hipStreamSynchronize(c->trace_stream));
     HIPCHK(hipMemcpyAsync(err, c->d_err, sizeof err, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     int rc = resolve_events(c);
