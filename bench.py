@@ -4,6 +4,10 @@
 A "step" is one SPPM pass at BASELINE config 2 geometry (Cornell box, 1920x1080, samples =
 supersamples = 1, alpha 0.7, initial r^2 = 25 = search r^2): eye pass over every pixel, 1M photons
 per GPU traced and applied to the hitpoints with the reference's per-photon update, image resolve.
+The timed region is a FRESH render: passes 0..K-1 (default K = 256, the whole of config 2: "1M
+photons/pass x 256 passes on one MI355X"); the W warmup passes run before it on a scratch context of
+the same size (clocks, first touch), so they are not part of the render.  Pass cost falls as the
+radii shrink (pass 0 is ~10x a late pass), so K matters and is reported in config.workload.
 Nothing is uploaded inside the timed region (scene and state are resident in HBM).
 
     python bench.py --gpus 1 --steps K --warmup W
@@ -51,7 +55,7 @@ def cpu_baseline(width, height, photons, seconds_target=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=256)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
@@ -76,28 +80,28 @@ def main():
     from raytracer_amd.parallel import ShardedSppm
 
     W, H, M = args.width, args.height, args.photons
-    job = ShardedSppm(W, H, photons_per_rank=M, rank=rank, world=world)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    step = 0
-    for _ in range(args.warmup):
-        job.step(step)
-        step += 1
-    job.ctx.check()
+    if args.warmup > 0:  # untimed: a scratch render of W passes
+        scratch = ShardedSppm(W, H, photons_per_rank=M, rank=rank, world=world)
+        for i in range(args.warmup):
+            scratch.step(i)
+        scratch.ctx.check()
+        scratch.close()
+    job = ShardedSppm(W, H, photons_per_rank=M, rank=rank, world=world)
     job.ctx.set_timing(True)
     c0 = job.ctx.counters()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        job.step(step)
-        step += 1
+    for i in range(args.steps):
+        job.step(i)
+    job.ctx.check()   # drains the tracer's stream too
     barrier()
     dt = time.perf_counter() - t0
-    job.ctx.check()
     c1 = job.ctx.counters()
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
     # per-rank counter deltas summed over ranks (each rank applies updates to its own hitpoints)
@@ -121,17 +125,17 @@ def main():
             "value": photons_total / dt, "unit": "photons/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"Cornell-box SPPM {W}x{H}, {M} photons/pass/GPU, passes {args.warmup}..{args.warmup + args.steps - 1} "
+            "config": {"workload": f"Cornell-box SPPM {W}x{H}, {M} photons/pass/GPU, passes 0..{args.steps - 1} "
                                    f"of a fresh render, alpha 0.7, initial r^2 25, search r^2 25, per-photon update (sppm2.h), "
                                    f"XorShift streams", "photons_per_pass": M * world, "width": W, "height": H,
                        "parallelism": job.describe()},
             "hitpoint_updates_per_s": upd / dt, "rays_per_s": rays / dt, "records_per_photon": records / max(1.0, float(M) * args.steps * (world if job.replicated_trace else 1)),
             "updates_per_photon": upd / photons_total,
-            "roofline": {"bound": "hbm", "kernel": "k_gather", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "k_gather_tiles", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": None,
                          "launches": int(g_launch), "avg_launch_ms": g_ns / 1e6 / g_launch,
                          "alg_bytes_per_launch": alg_bytes / g_launch,
-                         "note": "rank 0; algorithmic bytes = 28 B x candidate pairs examined + 32 B x accepted updates (SURVEY 8d)"},
+                         "note": "rank 0; algorithmic bytes = 28 B x (record, hitpoint) pairs distance-tested + 32 B x accepted updates (SURVEY 8d); launch durations from HIP events on the kernel's stream"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(W, H, M)

@@ -151,8 +151,8 @@ int sppm_download_tile_order(sppm_ctx* ctx, int32_t* h_order, int64_t* n);
 int sppm_accept_tap(sppm_ctx* ctx, int64_t cap);
 int sppm_download_accepted(sppm_ctx* ctx, uint64_t* h_key, int32_t* h_pix, int64_t* n);
 
-/* counters since creation: [0] rays cast, [1] photons traced, [2] photon-hit records, [3] records
- * enumerated from grid cells by the gather, [4] accepted hitpoint updates, [5] gather batches,
+/* counters since creation: [0] rays cast, [1] photons traced, [2] photon-hit records, [3] (record, hitpoint)
+ * pairs whose distance test ran in the gather, [4] accepted hitpoint updates, [5] gather batches,
  * [6] nanoseconds of device time in the gather kernel (HIP events on the context's stream, when
  * timing is on), [7] gather kernel launches timed, [8] in-region candidates staged, [9] staging rounds,
  * [10] live tile launches, [11] reserved. */

@@ -316,6 +316,7 @@ __global__ void __launch_bounds__(256) k_gather_tiles(HpArrays hp, DevScene sc, 
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const int64_t cap = rec.cap;
     unsigned int c_cand = 0, c_sel = 0, c_acc = 0, c_round = 0;  // wave-uniform tallies except c_acc (per lane)
+    unsigned long long c_pairs = 0;
     unsigned long long st_scan = 0, st_rank = 0, st_apply = 0;   // diagnostic build only (STAMPS)
 #define TSTAMP() (STAMPS ? (unsigned long long)__builtin_amdgcn_s_memtime() : 0ull)
 
@@ -329,6 +330,7 @@ __global__ void __launch_bounds__(256) k_gather_tiles(HpArrays hp, DevScene sc, 
     const bool inc = live && ((remaining >> lane) & 1ull) && fabs(hpos.x - sx) <= tp.cluster_d && fabs(hpos.y - sy) <= tp.cluster_d &&
                      fabs(hpos.z - sz) <= tp.cluster_d;
     remaining &= ~__ballot(inc);
+    const unsigned int n_inc = (unsigned int)__popcll(__ballot(inc));
     const double bx0 = wave_min_d(inc ? hpos.x : BIG), bx1 = wave_max_d(inc ? hpos.x : -BIG);
     const double by0 = wave_min_d(inc ? hpos.y : BIG), by1 = wave_max_d(inc ? hpos.y : -BIG);
     const double bz0 = wave_min_d(inc ? hpos.z : BIG), bz1 = wave_max_d(inc ? hpos.z : -BIG);
@@ -406,6 +408,7 @@ __global__ void __launch_bounds__(256) k_gather_tiles(HpArrays hp, DevScene sc, 
             if (sel_n > 0) {
                 __builtin_amdgcn_wave_barrier();
                 c_sel += (unsigned int)sel_n;
+                c_pairs += (unsigned long long)sel_n * n_inc;  // (record, hitpoint) pairs whose distance test runs
                 c_round++;
                 // ---- one candidate per lane: load it, rank it by key
                 const bool own = lane < sel_n;
@@ -495,7 +498,8 @@ __global__ void __launch_bounds__(256) k_gather_tiles(HpArrays hp, DevScene sc, 
     }
     for (int off = 32; off > 0; off >>= 1) c_acc += __shfl_down(c_acc, off);
     if (lane == 0) {
-        if (c_cand) atomicAdd(&counters[3], (unsigned long long)c_cand);
+        if (c_pairs) atomicAdd(&counters[3], c_pairs);
+        if (c_cand) atomicAdd(&counters[14], (unsigned long long)c_cand);
         if (c_acc) atomicAdd(&counters[4], (unsigned long long)c_acc);
         if (c_sel) atomicAdd(&counters[5], (unsigned long long)c_sel);
         if (c_round) atomicAdd(&counters[6], (unsigned long long)c_round);

@@ -1131,7 +1131,7 @@ static int gather_tiles(sppm_ctx* c)
     if (dbg)
         fprintf(stderr, "[sppm] batch %lld photons: %u items for %d tiles (mean est %.0f), gather %.2f ms, max per tile: sel %llu cand %llu rounds %llu cycles %llu (avg cycles %.0f); cell %.3f grid %dx%dx%d S=%d B=%lld rounds/tile-slab %.2f sel/tile-slab %.2f cand/sel %.2f next B %lld\n",
                 (long long)range, n_items, c->n_owned, mean_est, dbg_ms, cnt1[8], cnt1[9], cnt1[10], cnt1[11], (double)cnt1[12] / std::max(1.0, tiles_run), cell, g.nx, g.ny, g.nz, g.S, (long long)B, (double)(cnt1[6] - cnt0[6]) / std::max(1.0, tiles_run * S),
-                (double)(cnt1[5] - cnt0[5]) / std::max(1.0, tiles_run * S), (double)(cnt1[3] - cnt0[3]) / std::max(1.0, (double)(cnt1[5] - cnt0[5])),
+                (double)(cnt1[5] - cnt0[5]) / std::max(1.0, tiles_run * S), (double)(cnt1[14]) / std::max(1.0, (double)(cnt1[5] - cnt0[5])),
                 (long long)c->slab_B);
     if (dbg && getenv("SPPM_STAMPS"))
         fprintf(stderr, "[sppm]   stamps (share of item cycles): scan %.1f%% rank+load %.1f%% apply %.1f%%\n", 100.0 * cnt1[16] / std::max(1.0, (double)cnt1[12]),
