@@ -110,14 +110,18 @@ int sppm_eye_pass(sppm_ctx* ctx, int32_t pass);
 int sppm_photon_pass(sppm_ctx* ctx, int32_t pass, int64_t first, int64_t count);
 
 /* The two halves of a photon pass, for multi-GPU use (trace a shard, exchange records, gather):
- * sppm_trace appends the photon-hit records of photons [first, first+count) to the context's
- * record buffer; sppm_records gives the device arrays (SoA: d_key[n], d_f[9][cap]: position,
- * geometric normal, flux) so they can be all-gathered; sppm_set_records installs an external
- * record set; sppm_gather applies the installed records and clears them. */
+ * sppm_trace appends the photon-hit records of photons [first, first+count) of a pass to the context's
+ * current record buffer; sppm_gather bins the buffer's records and applies them to this rank's
+ * hitpoints in key order, then clears the buffer.
+ * sppm_pack_records moves the buffer's records into d_rows[n][10] (row = key bits, position,
+ * geometric normal, flux; any order) and clears the buffer -- what a rank contributes to an all-gather;
+ * if cap_rows is too small nothing is cleared, n holds the count needed and SPPM_ERR_OVERFLOW returns.
+ * sppm_append_records adds rows (typically another rank's) to the buffer; [photon_first, photon_end) is
+ * the photon index range those rows can come from (it sizes the time slabs of the gather). */
 int sppm_trace(sppm_ctx* ctx, int32_t pass, int64_t first, int64_t count);
-int sppm_records(sppm_ctx* ctx, uint64_t** d_key, double** d_f, int64_t* n, int64_t* cap);
-int sppm_set_record_count(sppm_ctx* ctx, int64_t n);
 int sppm_gather(sppm_ctx* ctx);
+int sppm_pack_records(sppm_ctx* ctx, double* d_rows, int64_t cap_rows, int64_t* n);
+int sppm_append_records(sppm_ctx* ctx, const double* d_rows, int64_t n, int64_t photon_first, int64_t photon_end);
 
 /* End-of-pass update of rule 1 (src/stochastic_ppm.h:721-741); a no-op for rule 0. */
 int sppm_end_pass(sppm_ctx* ctx);

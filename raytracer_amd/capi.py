@@ -10,7 +10,7 @@ LIB_PATH = os.path.join(_HERE, "libsppm_hip.so")
 
 SYMBOLS = [
     "sppm_last_error", "sppm_device_count", "sppm_create", "sppm_destroy", "sppm_camera_rays", "sppm_intersect",
-    "sppm_eye_pass", "sppm_photon_pass", "sppm_trace", "sppm_records", "sppm_set_record_count", "sppm_gather",
+    "sppm_eye_pass", "sppm_photon_pass", "sppm_trace", "sppm_pack_records", "sppm_append_records", "sppm_gather",
     "sppm_end_pass", "sppm_resolve", "sppm_hdr_pixels", "sppm_save_hdr_file", "sppm_save_ppm_file", "sppm_check",
     "sppm_download_hitpoints", "sppm_download_records", "sppm_download_tile_order", "sppm_accept_tap", "sppm_download_accepted", "sppm_counters",
     "sppm_set_timing",
@@ -57,8 +57,8 @@ def lib():
     L.sppm_eye_pass.argtypes = [vp, i32]
     L.sppm_photon_pass.argtypes = [vp, i32, i64, i64]
     L.sppm_trace.argtypes = [vp, i32, i64, i64]
-    L.sppm_records.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(i64), C.POINTER(i64)]
-    L.sppm_set_record_count.argtypes = [vp, i64]
+    L.sppm_pack_records.argtypes = [vp, vp, i64, C.POINTER(i64)]
+    L.sppm_append_records.argtypes = [vp, vp, i64, i64, i64]
     L.sppm_gather.argtypes = [vp]
     L.sppm_end_pass.argtypes = [vp]
     L.sppm_resolve.argtypes = [vp, i32, i64, vp]

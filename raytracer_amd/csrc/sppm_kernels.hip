@@ -609,6 +609,43 @@ __global__ void k_hdr_pixels(const double* __restrict__ rgb, int64_t n, uint8_t*
     out[4 * i] = px[0]; out[4 * i + 1] = px[1]; out[4 * i + 2] = px[2]; out[4 * i + 3] = px[3];
 }
 
+// ---- record exchange between ranks: SoA buffer <-> packed rows of 10 doubles (key bits, 9 fields) -------
+__global__ void k_pack_records(RecArrays rec, const unsigned long long* __restrict__ rec_count, double* __restrict__ rows, int64_t cap_rows,
+                               unsigned long long* __restrict__ n_out)
+{
+    const int64_t n = min((int64_t)*rec_count, rec.cap);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const unsigned long long key = rec.key[i];
+        if (key == REC_INVALID) continue;
+        const unsigned long long at = atomicAdd(n_out, 1ull);
+        if ((int64_t)at >= cap_rows) continue;  // counted, not stored: the host reports the overflow
+        double* r = rows + 10 * at;
+        r[0] = __longlong_as_double((long long)key);
+#pragma unroll
+        for (int c = 0; c < 9; c++) r[1 + c] = rec.f[c * rec.cap + i];
+    }
+}
+__global__ void k_append_records(RecArrays rec, unsigned long long* __restrict__ rec_count, const double* __restrict__ rows, int64_t n,
+                                 int32_t* __restrict__ err)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool has = i < n;
+    const unsigned long long m = __ballot(has);
+    if (m == 0) return;
+    const int lane = threadIdx.x & 63;
+    unsigned long long base = 0;
+    if (lane == __ffsll((long long)m) - 1) base = atomicAdd(rec_count, (unsigned long long)__popcll(m));
+    base = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) |
+           (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)base);
+    if (!has) return;
+    const int64_t slot = (int64_t)base + __popcll(m & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
+    if (slot >= rec.cap) { err[0] = 1; return; }
+    const double* r = rows + 10 * i;
+    rec.key[slot] = (unsigned long long)__double_as_longlong(r[0]);
+#pragma unroll
+    for (int c = 0; c < 9; c++) rec.f[c * rec.cap + slot] = r[1 + c];
+}
+
 #include "sppm_gather_tiles.hpp"
 
 // ================================ host side / C ABI =================================================
@@ -924,28 +961,43 @@ extern "C" int sppm_trace(sppm_ctx* c, int32_t pass, int64_t first, int64_t coun
     return SPPM_OK;
 }
 
-extern "C" int sppm_records(sppm_ctx* c, uint64_t** d_key, double** d_f, int64_t* n, int64_t* cap)
+// number of record slots in use in the current buffer (holes included)
+static int slots_in_use(sppm_ctx* c, int64_t* n)
 {
-    if (!c) return fail(SPPM_ERR_INVALID, "sppm_records: null context");
-    if (n) {
-        unsigned long long cnt = 0;
-        HIPCHK(hipMemcpyAsync(&cnt, c->d_rec_count, sizeof cnt, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
-        if ((int64_t)cnt > c->rec_u.cap) return fail(SPPM_ERR_OVERFLOW, "record buffer overflow: raise SPPM_RECORD_CAP or lower SPPM_BATCH_PHOTONS");
-        *n = (int64_t)cnt;
-    }
-    if (d_key) *d_key = c->rec_u.key;
-    if (d_f) *d_f = c->rec_u.f;
-    if (cap) *cap = c->rec_u.cap;
+    unsigned long long cnt = 0;
+    HIPCHK(hipMemcpyAsync(&cnt, c->d_rec_count, sizeof cnt, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if ((int64_t)cnt > c->rec_u.cap) return fail(SPPM_ERR_OVERFLOW, "record buffer overflow: raise SPPM_RECORD_CAP or lower SPPM_BATCH_PHOTONS");
+    *n = (int64_t)cnt;
+    return 0;
+}
+
+extern "C" int sppm_pack_records(sppm_ctx* c, double* d_rows, int64_t cap_rows, int64_t* n)
+{
+    if (!c || !n || cap_rows < 0 || (cap_rows > 0 && !d_rows)) return fail(SPPM_ERR_INVALID, "sppm_pack_records: bad argument");
+    HIPCHK(hipMemsetAsync(c->d_r2max, 0, sizeof(unsigned long long), c->stream));  // reused as the row counter
+    hipLaunchKernelGGL(k_pack_records, dim3(1024), dim3(256), 0, c->stream, c->rec_u, c->d_rec_count, d_rows, cap_rows, c->d_r2max);
+    HIPCHK(hipGetLastError());
+    unsigned long long cnt = 0;
+    HIPCHK(hipMemcpyAsync(&cnt, c->d_r2max, sizeof cnt, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    *n = (int64_t)cnt;
+    if ((int64_t)cnt > cap_rows) return fail(SPPM_ERR_OVERFLOW, "sppm_pack_records: the row buffer is too small (n holds the count needed)");
+    HIPCHK(hipMemsetAsync(c->d_rec_count, 0, sizeof(unsigned long long), c->stream));
+    c->rec_first = c->rec_end = 0;
     return SPPM_OK;
 }
 
-extern "C" int sppm_set_record_count(sppm_ctx* c, int64_t n)
+extern "C" int sppm_append_records(sppm_ctx* c, const double* d_rows, int64_t n, int64_t photon_first, int64_t photon_end)
 {
-    if (!c || n < 0 || n > c->rec_u.cap) return fail(SPPM_ERR_INVALID, "sppm_set_record_count: count out of range");
-    const unsigned long long v = (unsigned long long)n;
-    HIPCHK(hipMemcpyAsync(c->d_rec_count, &v, sizeof v, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    if (!c || n < 0 || (n > 0 && !d_rows) || photon_first < 0 || photon_end < photon_first) return fail(SPPM_ERR_INVALID, "sppm_append_records: bad argument");
+    if (photon_end > photon_first) {
+        if (c->rec_end == c->rec_first) { c->rec_first = photon_first; c->rec_end = photon_end; }
+        else { c->rec_first = std::min(c->rec_first, photon_first); c->rec_end = std::max(c->rec_end, photon_end); }
+    }
+    if (n == 0) return SPPM_OK;
+    hipLaunchKernelGGL(k_append_records, dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->rec_u, c->d_rec_count, d_rows, n, c->d_err);
+    HIPCHK(hipGetLastError());
     return SPPM_OK;
 }
 
@@ -1392,7 +1444,7 @@ extern "C" int sppm_download_records(sppm_ctx* c, uint64_t* h_key, double* h_f, 
 {
     if (!c || !n) return fail(SPPM_ERR_INVALID, "sppm_download_records: null argument");
     int64_t cnt = 0;
-    int rc = sppm_records(c, nullptr, nullptr, &cnt, nullptr);
+    int rc = slots_in_use(c, &cnt);
     if (rc) return rc;
     std::vector<uint64_t> key((size_t)cnt);
     std::vector<double> f(9 * (size_t)cnt);

@@ -47,6 +47,8 @@ class ShardedSppm:
         cfg = sppm.make_config(width, height, photons_per_pass=self.M, tile_first=rank, tile_stride=world, **cfg_kw)
         self.ctx = sppm.SppmContext(cfg, spheres)
         self.image = None
+        self._rows = self._all = None
+        self.batch_photons = 1 << 20
 
     def describe(self):
         if self.world == 1:
@@ -67,7 +69,30 @@ class ShardedSppm:
         return self.image
 
     def _photon_pass_allgather(self, i):
-        raise NotImplementedError("exchange='allgather' needs sppm_pack_records/sppm_append_records (next step)")
+        """Rank r traces photons [r*M_rank, (r+1)*M_rank) of the pass in batches; after each batch the
+        packed records of all ranks are combined with one RCCL all-gather (padded to the largest
+        count) and every rank applies all of them to its own hitpoints."""
+        import torch
+        import torch.distributed as dist
+        ctx = self.ctx
+        dev = ctx.device
+        batch = min(self.M_rank, self.batch_photons)
+        rows_cap = 4 * batch + 4096
+        if self._rows is None or self._rows.shape[0] < rows_cap:
+            self._rows = torch.empty((rows_cap, 10), dtype=torch.float64, device=dev)
+            self._all = torch.empty((self.world, rows_cap, 10), dtype=torch.float64, device=dev)
+        for off in range(0, self.M_rank, batch):
+            n = min(batch, self.M_rank - off)
+            ctx.trace(i, self.rank * self.M_rank + off, n)
+            cnt = ctx.pack_records(self._rows)
+            counts = exchange_counts(cnt, self.world, dev)
+            m = int(max(counts))
+            # one collective per batch: every rank's rows, padded to the largest count
+            out = self._all[:, :m, :].contiguous() if m < rows_cap else self._all
+            dist.all_gather_into_tensor(out.view(self.world * m, 10), self._rows[:m].contiguous())
+            for r in range(self.world):
+                ctx.append_records(out[r], counts[r], r * self.M_rank + off, r * self.M_rank + off + n)
+            ctx.gather()
 
     def gather_image(self):
         """Full image on every rank: every rank's resolve is valid on the tiles it owns; one
@@ -76,9 +101,9 @@ class ShardedSppm:
         import torch.distributed as dist
         if self.world == 1:
             return self.image
-        out = torch.empty((self.world,) + tuple(self.image.shape), dtype=torch.float64, device=self.image.device)
-        dist.all_gather_into_tensor(out, self.image.contiguous())
-        return select_by_owner(out, owner_of_pixels(self.W, self.H, self.world))
+        out = torch.empty((self.world * self.P, 3), dtype=torch.float64, device=self.image.device)
+        dist.all_gather_into_tensor(out, self.image.contiguous())  # concatenated along dim 0 (the form gloo accepts too)
+        return select_by_owner(out.view(self.world, self.P, 3), owner_of_pixels(self.W, self.H, self.world))
 
     def close(self):
         self.ctx.close()
@@ -89,3 +114,13 @@ def select_by_owner(stacked, owner):
     import torch
     idx = torch.as_tensor(owner, dtype=torch.int64, device=stacked.device)
     return stacked[idx, torch.arange(stacked.shape[1], device=stacked.device)]
+
+
+def exchange_counts(count, world, device):
+    """all-gather one integer per rank (works with nccl on GPU tensors and gloo on CPU tensors)."""
+    import torch
+    import torch.distributed as dist
+    mine = torch.tensor([count], dtype=torch.int64, device=device)
+    out = torch.empty((world,), dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(out, mine)
+    return [int(x) for x in out.tolist()]

@@ -119,15 +119,15 @@ class SppmContext:
         return out
 
     # ---- records (multi-GPU exchange) ------------------------------------------------------------
-    def records(self):
-        """(device pointer of keys, device pointer of f[9][cap], count, cap)."""
-        k, f = C.c_void_p(), C.c_void_p()
-        n, cap = C.c_int64(), C.c_int64()
-        capi.check(self.L.sppm_records(self.h, C.byref(k), C.byref(f), C.byref(n), C.byref(cap)))
-        return k.value, f.value, n.value, cap.value
+    def pack_records(self, rows):
+        """Move the buffer's records into the torch tensor rows[cap][10] (float64, this device);
+        returns the count."""
+        n = C.c_int64()
+        capi.check(self.L.sppm_pack_records(self.h, rows.data_ptr(), rows.shape[0], C.byref(n)))
+        return n.value
 
-    def set_record_count(self, n):
-        capi.check(self.L.sppm_set_record_count(self.h, n))
+    def append_records(self, rows, n, photon_first, photon_end):
+        capi.check(self.L.sppm_append_records(self.h, rows.data_ptr(), n, photon_first, photon_end))
 
     # ---- taps ------------------------------------------------------------------------------------
     def hitpoints(self):

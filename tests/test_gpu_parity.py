@@ -184,3 +184,98 @@ def test_per_pass_rule_matches_oracle():
         _same(ctx.resolve(i, M).cpu().numpy(), orc.resolve(i, M), f"pass {i} image")
     ctx.check()
     ctx.close()
+
+
+def test_record_exchange_equals_local_tracing():
+    """The all-gather path of a 2-rank run, emulated with two contexts on one GPU: each 'rank' traces
+    half of the photons, the packed records are exchanged through sppm_pack_records /
+    sppm_append_records, every rank gathers for its own tiles.  Merged by owner the result equals a
+    single context that did everything itself, bit for bit."""
+    import torch
+    from raytracer_amd.parallel import owner_of_pixels
+    W, H, M = 64, 48, 20000
+    full = sppm.SppmContext(sppm.make_config(W, H, photons_per_pass=M))
+    ranks = [sppm.SppmContext(sppm.make_config(W, H, photons_per_pass=M, tile_first=r, tile_stride=2)) for r in range(2)]
+    rows = [torch.empty((8 * M, 10), dtype=torch.float64, device="cuda") for _ in range(2)]
+    half = M // 2
+    for i in range(2):
+        full.eye_pass(i)
+        full.photon_pass(i, M)
+        cnt = []
+        for r, c in enumerate(ranks):
+            c.eye_pass(i)
+            c.trace(i, r * half, half)
+            cnt.append(c.pack_records(rows[r]))
+        assert sum(cnt) > 0
+        for c in ranks:
+            for r in range(2):
+                c.append_records(rows[r], cnt[r], r * half, (r + 1) * half)
+            c.gather()
+    for c in [full] + ranks:
+        c.check()
+    own = owner_of_pixels(W, H, 2)
+    ref = full.hitpoints()
+    got = [c.hitpoints() for c in ranks]
+    for k in ("n", "r2", "flux"):
+        merged = np.where(own.reshape((-1,) + (1,) * (ref[k].ndim - 1)) == 0, got[0][k], got[1][k])
+        _same(merged, ref[k], k)
+    for c in [full] + ranks:
+        c.close()
+
+
+def test_pack_reports_a_short_row_buffer():
+    import torch
+    from raytracer_amd import capi
+    ctx = sppm.SppmContext(sppm.make_config(64, 48, photons_per_pass=4096))
+    ctx.eye_pass(0)
+    ctx.trace(0, 0, 4096)
+    small = torch.empty((8, 10), dtype=torch.float64, device="cuda")
+    with pytest.raises(capi.SppmError):
+        ctx.pack_records(small)
+    big = torch.empty((40000, 10), dtype=torch.float64, device="cuda")
+    n = ctx.pack_records(big)          # nothing was lost by the failed call
+    key, f = ctx.download_records()
+    assert n > 0 and len(key) == 0     # packed -> the buffer is empty now
+    ctx.close()
+
+
+@pytest.mark.parametrize("wh", [(1920, 1080)])
+def test_full_size_invariants(wh):
+    """BASELINE config 2 geometry (1080p, 1M photons per pass), where the oracle would take minutes:
+    size-independent properties of the reference's update rule.
+      * r^2 is a function of the photon count alone: r2 = r0^2 * prod_{k=1}^{N-1} (k a + a)/(k a + 1)
+        evaluated in the reference's order (src/sppm2.h:398-407) -- checked bit for bit;
+      * sum of N over hitpoints == accepted updates counted by the kernel;
+      * a second run gives identical bits (no atomics on hitpoint data, order fixed by keys);
+      * the image is finite and non-negative."""
+    W, H = wh
+    M = 1_000_000
+    outs = []
+    for rep_ in range(2):
+        ctx = sppm.SppmContext(sppm.make_config(W, H, photons_per_pass=M))
+        for i in range(2):
+            ctx.eye_pass(i)
+            ctx.photon_pass(i, M)
+        ctx.check()
+        s = ctx.hitpoints()
+        img = ctx.resolve(1, M).cpu().numpy()
+        cnt = ctx.counters()
+        ctx.close()
+        outs.append((s, img, cnt))
+    s, img, cnt = outs[0]
+    v = s["valid"] > 0
+    assert int(s["n"][v].sum()) == cnt["updates"]
+    nmax = int(s["n"].max())
+    alpha = 0.7
+    table = np.empty(nmax + 1)
+    r2 = 25.0
+    table[0] = r2
+    for k in range(nmax):       # state after k+1 accepted photons
+        g = 1.0 if k == 0 else (k * alpha + alpha) / (k * alpha + 1.0)
+        r2 = r2 * g
+        table[k + 1] = r2
+    _same(s["r2"][v], table[s["n"][v]], "r2 as a function of N")
+    assert np.isfinite(img).all() and (img >= 0).all()
+    for k in ("n", "r2", "flux", "ld"):
+        _same(outs[1][0][k], s[k], f"run-to-run {k}")
+    _same(outs[1][1], img, "run-to-run image")
