@@ -52,6 +52,21 @@ def cpu_baseline(width, height, photons, seconds_target=12.0):
                       f"{done} photons in {t_ph:.1f} s, {upd} hitpoint updates ({upd / t_ph:.3g} updates/s)"}
 
 
+def measured_traffic(width, height, photons, steps):
+    """HBM bytes per k_gather_tiles launch from the committed PMC passes (profiles/r01_pmc_traffic.json:
+    FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3 --pmc runs of this script, FETCH_SIZE
+    doubled as MI355X_MICROARCH.md prescribes for gfx950).  Counters cannot be read from inside a
+    normal run, so the figure is only reported for the workload it was measured on; otherwise null."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            t = json.load(f)
+    except OSError:
+        return None
+    if [width, height, photons, steps] != [t["width"], t["height"], t["photons"], t["steps"]]:
+        return None
+    return t["gather_bytes_per_launch"]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -120,6 +135,10 @@ def main():
         # 28 B per candidate hitpoint/record pair examined, +32 B per accepted update
         alg_bytes = 28.0 * cand0 + 32.0 * upd0
         achieved = alg_bytes / max(g_ns, 1) if g_ns else 0.0  # bytes/ns == GB/s
+        t_ns = c1["trace_ns"] - c0["trace_ns"]
+        t_launch = max(1, c1["trace_launches"] - c0["trace_launches"])
+        p_rays = c1["photon_rays"] - c0["photon_rays"]
+        tflops = 219.0 * p_rays / max(t_ns, 1) / 1e3 if t_ns else 0.0  # flop/ns = GFLOP/s -> TFLOP/s
         out = {
             "metric": "photons traced/sec + hitpoint updates/sec (whole node), SPPM Cornell 1080p",
             "value": photons_total / dt, "unit": "photons/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -137,6 +156,14 @@ def main():
                          "alg_bytes_per_launch": alg_bytes / g_launch,
                          "note": "rank 0; algorithmic bytes = 28 B x (record, hitpoint) pairs distance-tested + 32 B x accepted updates (SURVEY 8d); launch durations from HIP events on the kernel's stream"},
         }
+        # second fraction asked for by SURVEY 8(d): the intersection work of the photon tracer against the
+        # FP64 vector peak.  The tracer runs on its own stream CONCURRENTLY with the gather, so its launch
+        # durations include the time it shares the CUs.
+        out["roofline_trace"] = {"bound": "valu_f64", "kernel": "k_photon_trace", "achieved": tflops, "peak": 78.6, "unit": "TFLOP/s",
+                                 "frac": tflops / 78.6, "launches": int(t_launch), "avg_launch_ms": t_ns / 1e6 / t_launch,
+                                 "rays_per_launch": p_rays / t_launch,
+                                 "note": "rank 0; 219 flop per ray (20 x 9 spheres + 19, SURVEY 8d) x rays cast by photon tracing; overlapped with the gather"}
+        out["roofline"]["traffic"] = measured_traffic(W, H, M, args.steps)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(W, H, M)
         print(json.dumps(out), flush=True)

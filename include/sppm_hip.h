@@ -73,7 +73,14 @@ typedef struct sppm_config {
                                         (tiles numbered row-major over the image-index grid); 0,0 = all tiles.
                                         The eye pass and tracing always cover what the calls ask for. */
     int32_t check_gather_max;
-    int32_t reserved_[3];
+    int32_t sampler;         /* 0: one edupt::XorShift stream (src/random.h:9-33) per (pass, pixel) and per photon --
+                                the parallel, GPU-count independent definition (default).
+                                1: the reference's own sampler (src/sampler/value_sampler.h:8-15): ONE sequential
+                                std::mt19937 stream for all eye passes seeded seed_eye (src/sppm2.h:621) and one per
+                                photon pass seeded seed_photon + pass (src/sppm2.h:530; the reference takes both
+                                seeds from std::random_device).  Reproduces the reference's image for matched
+                                seeds; single GPU, whole passes only, for validation rather than speed. */
+    int32_t reserved_[2];
 } sppm_config;
 
 typedef struct sppm_ctx sppm_ctx;
@@ -159,8 +166,10 @@ int sppm_download_accepted(sppm_ctx* ctx, uint64_t* h_key, int32_t* h_pix, int64
  * pairs whose distance test ran in the gather, [4] accepted hitpoint updates, [5] gather batches,
  * [6] nanoseconds of device time in the gather kernel (HIP events on the context's stream, when
  * timing is on), [7] gather kernel launches timed, [8] in-region candidates staged, [9] staging rounds,
- * [10] live tile launches, [11] reserved. */
-int sppm_counters(sppm_ctx* ctx, uint64_t h_out[12]);
+ * [10] live tile launches, [11] nanoseconds of device time in the photon-trace kernel (HIP events on the
+ * stream it runs on), [12] trace kernel launches timed, [13] rays cast by photon tracing ([0] includes
+ * them), [14..15] reserved. */
+int sppm_counters(sppm_ctx* ctx, uint64_t h_out[16]);
 int sppm_set_timing(sppm_ctx* ctx, int32_t on);
 
 #ifdef __cplusplus

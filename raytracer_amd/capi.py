@@ -32,7 +32,7 @@ class SppmConfig(C.Structure):
                 ("seed_eye", C.c_uint32), ("seed_photon", C.c_uint32),
                 ("photons_per_pass", C.c_int64),
                 ("tile_first", C.c_int32), ("tile_stride", C.c_int32),
-                ("check_gather_max", C.c_int32), ("reserved_", C.c_int32 * 3)]
+                ("check_gather_max", C.c_int32), ("sampler", C.c_int32), ("reserved_", C.c_int32 * 2)]
 
 
 _LIB = None

@@ -54,6 +54,29 @@ struct XorShift {
     }
     // (double)next() / UINT_MAX, src/random.h:23 (can return exactly 1.0, as the reference's can)
     __device__ __forceinline__ double next01() { return (double)next() / 4294967295.0; }
+    // hooks of the sequential-stream samplers below (nothing to do for a per-path stream)
+    __device__ __forceinline__ void decision() {}
+    __device__ __forceinline__ bool stop() const { return false; }
+};
+
+// ---- the reference's own sampler: ONE sequential stream of uniform doubles ------------------------
+// (src/sampler/value_sampler.h:8-15: std::mt19937 + uniform_real_distribution<double>(0,1), shared by
+// every pixel of every eye pass / every photon of a photon pass).  The host generates the stream
+// (std::mt19937, same library code as the reference); a path reads it from the offset where the paths
+// before it stopped.  See "reference-stream mode" in sppm_kernels.hip for how those offsets are found
+// in parallel.
+struct StreamRng {
+    const double* u; int64_t pos, end;
+    __device__ __forceinline__ double next01() { const double v = pos < end ? u[pos] : 0.5; pos++; return v; }
+    __device__ __forceinline__ void decision() {}
+    __device__ __forceinline__ bool stop() const { return pos > end; }  // ran past the uploaded part: abandon the path
+};
+// Counts the draws of a path whose control flow does not depend on them, and flags the ones where it does.
+struct ProbeRng {
+    int count; bool dyn;
+    __device__ __forceinline__ double next01() { count++; return 0.5; }
+    __device__ __forceinline__ void decision() { dyn = true; }  // called right before a draw that steers the path
+    __device__ __forceinline__ bool stop() const { return dyn; }
 };
 __device__ __forceinline__ uint32_t fmix32(uint32_t h)
 {
@@ -131,7 +154,8 @@ __device__ __forceinline__ void basis(d3 w, d3& u, d3& v)
     v = cross(w, u);
 }
 // cosine_sampling, src/sppm2.h:138-144
-__device__ __forceinline__ d3 cosine_sampling(d3 w, d3 u, d3 v, XorShift& rng)
+template <class RNG>
+__device__ __forceinline__ d3 cosine_sampling(d3 w, d3 u, d3 v, RNG& rng)
 {
     const double u1 = 2 * SPPM_PI * rng.next01();
     const double u2 = rng.next01();
@@ -142,8 +166,9 @@ __device__ __forceinline__ d3 cosine_sampling(d3 w, d3 u, d3 v, XorShift& rng)
 }
 
 // next_event_est, src/radiance.h:29-70
+template <class RNG>
 __device__ __forceinline__ d3 next_event_est(const sppm_sphere* __restrict__ sp, int ns, const Hit& is, d3 on,
-                                             XorShift& rng, uint32_t& rays)
+                                             RNG& rng, uint32_t& rays)
 {
     if (is.object_id == 0) return mk(0, 0, 0);
     const double r1 = 2 * SPPM_PI * rng.next01();

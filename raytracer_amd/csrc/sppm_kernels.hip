@@ -25,6 +25,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <random>
 #include <string>
 #include <vector>
 
@@ -68,49 +69,53 @@ struct HpArrays {
 
 struct EyeParams {
     Camera cam; int W, H, samples, supersamples; int pass; uint32_t seed_eye; double initial_r2; int double_nee;
+    // reference-stream mode only
+    const double* u; int64_t u_len; uint32_t* cnt; unsigned long long* off; unsigned long long* total;
 };
 
-// One thread per pixel: the loops of src/sppm2.h:625-646 around create_point_loop (:156-315).
-__global__ void __launch_bounds__(256) k_eye_pass(DevScene sc, EyeParams ep, HpArrays hp, unsigned long long* __restrict__ counters)
+// One pixel of an eye pass: the sy/sx/s loops of src/sppm2.h:628-643 around create_point_loop
+// (:156-315).  t = y*W + x is the pixel's place in the reference's render order.  COMMIT = false runs
+// the same paths without storing anything (used to count draws).
+template <class RNG, bool COMMIT>
+__device__ __forceinline__ void eye_pixel(const DevScene& sc, const EyeParams& ep, const HpArrays& hp, int t, RNG& rng, uint32_t& rays)
 {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int P = ep.W * ep.H;
-    uint32_t rays = 0;
-    if (t < P) {
-        const int x = t % ep.W, y = t / ep.W;
-        const int index = (ep.H - y - 1) * ep.W + x;
-        XorShift rng = make_stream(ep.seed_eye, (uint64_t)ep.pass * (uint64_t)P + (uint64_t)index);
-        d3 ld = mk(hp.ld[index], hp.ld[P + index], hp.ld[2 * P + index]);
-        int valid = hp.valid[index];
-        for (int sy = 0; sy < ep.supersamples; sy++)
-            for (int sx = 0; sx < ep.supersamples; sx++)
-                for (int s = 0; s < ep.samples; s++) {
-                    d3 org, dir;
-                    camera_ray(ep.cam, x, y, sx, sy, org, dir);
-                    int depth = -1;
-                    bool direct = true;
-                    d3 weight = mk(1, 1, 1);
-                    for (;;) {
-                        depth++;
-                        Hit is;
-                        rays++;
-                        if (!intersect_scene(sc.sp, sc.ns, org, dir, is)) break;
-                        const sppm_sphere* obj = &sc.sp[is.object_id];
-                        const d3 color = ld3(obj->color);
-                        const int type = obj->reflection_type;
-                        const d3 on = dot(is.normal, dir) < 0.0 ? is.normal : is.normal * -1.0;
-                        if (direct) ld = ld + had(weight, ld3(obj->emission));
-                        direct = type != SPPM_DIFFUSE;
-                        if (type == SPPM_DIFFUSE) {
-                            const d3 est = next_event_est(sc.sp, sc.ns, is, on, rng, rays);
-                            ld = ld + had(weight, est);
-                            // create or overwrite the pixel's hitpoint (src/sppm2.h:204-227)
+    const int x = t % ep.W, y = t / ep.W;
+    const int index = (ep.H - y - 1) * ep.W + x;
+    d3 ld = mk(hp.ld[index], hp.ld[P + index], hp.ld[2 * P + index]);
+    int valid = hp.valid[index];
+    for (int sy = 0; sy < ep.supersamples; sy++)
+        for (int sx = 0; sx < ep.supersamples; sx++)
+            for (int s = 0; s < ep.samples; s++) {
+                d3 org, dir;
+                camera_ray(ep.cam, x, y, sx, sy, org, dir);
+                int depth = -1;
+                bool direct = true;
+                d3 weight = mk(1, 1, 1);
+                for (;;) {
+                    depth++;
+                    Hit is;
+                    rays++;
+                    if (!intersect_scene(sc.sp, sc.ns, org, dir, is)) break;
+                    const sppm_sphere* obj = &sc.sp[is.object_id];
+                    const d3 color = ld3(obj->color);
+                    const int type = obj->reflection_type;
+                    const d3 on = dot(is.normal, dir) < 0.0 ? is.normal : is.normal * -1.0;
+                    if (direct) ld = ld + had(weight, ld3(obj->emission));
+                    direct = type != SPPM_DIFFUSE;
+                    if (type == SPPM_DIFFUSE) {
+                        const d3 est = next_event_est(sc.sp, sc.ns, is, on, rng, rays);
+                        ld = ld + had(weight, est);
+                        // create or overwrite the pixel's hitpoint (src/sppm2.h:204-227)
+                        if constexpr (COMMIT) {
                             hp.pos[index] = is.position.x; hp.pos[P + index] = is.position.y; hp.pos[2 * P + index] = is.position.z;
                             hp.nrm[index] = is.normal.x; hp.nrm[P + index] = is.normal.y; hp.nrm[2 * P + index] = is.normal.z;
                             hp.w[index] = weight.x; hp.w[P + index] = weight.y; hp.w[2 * P + index] = weight.z;
                             hp.obj[index] = is.object_id; hp.dist[index] = is.distance;
-                            if (!valid) {
-                                valid = 1;
+                        }
+                        if (!valid) {
+                            valid = 1;
+                            if constexpr (COMMIT) {
                                 hp.valid[index] = 1;
                                 hp.r2[index] = ep.initial_r2;
                                 hp.n[index] = 0;  // the reference leaves photon_count unset (src/sppm2.h:108-116); its call site passes 0
@@ -120,50 +125,139 @@ __global__ void __launch_bounds__(256) k_eye_pass(DevScene sc, EyeParams ep, HpA
                                     hp.phi[index] = 0.0; hp.phi[P + index] = 0.0; hp.phi[2 * P + index] = 0.0;
                                     hp.tau[index] = 0.0; hp.tau[P + index] = 0.0; hp.tau[2 * P + index] = 0.0;
                                 }
-                                // the reference's `break` leaves the switch only: fall into the roulette
-                                // block and go round again with the same ray (second direct sample)
-                                if (!ep.double_nee) goto path_done;
-                            } else
-                                goto path_done;
-                        } else if (type == SPPM_SPECULAR) {
-                            org = is.position;
-                            dir = reflect_dir(dir, is.normal);
+                            }
+                            // the reference's `break` leaves the switch only: fall into the roulette
+                            // block and go round again with the same ray (second direct sample)
+                            if (!ep.double_nee) goto path_done;
+                        } else
+                            goto path_done;
+                    } else if (type == SPPM_SPECULAR) {
+                        org = is.position;
+                        dir = reflect_dir(dir, is.normal);
+                        weight = had(weight, color);
+                    } else {
+                        const d3 rdir = reflect_dir(dir, is.normal);
+                        bool into; double nnt, Re; d3 tdir;
+                        org = is.position;
+                        if (!glass(dir, is.normal, on, true, into, nnt, tdir, Re)) {
+                            dir = rdir;
                             weight = had(weight, color);
                         } else {
-                            const d3 rdir = reflect_dir(dir, is.normal);
-                            bool into; double nnt, Re; d3 tdir;
-                            org = is.position;
-                            if (!glass(dir, is.normal, on, true, into, nnt, tdir, Re)) {
+                            const double nnt2 = nnt * nnt;
+                            const double Tr = (1.0 - Re) * nnt2;
+                            const double prob = 0.25 + 0.5 * Re;
+                            rng.decision();
+                            if (rng.next01() < prob) {
                                 dir = rdir;
-                                weight = had(weight, color);
+                                weight = had(weight, color * Re / prob);
                             } else {
-                                const double nnt2 = nnt * nnt;
-                                const double Tr = (1.0 - Re) * nnt2;
-                                const double prob = 0.25 + 0.5 * Re;
-                                if (rng.next01() < prob) {
-                                    dir = rdir;
-                                    weight = had(weight, color * Re / prob);
-                                } else {
-                                    dir = tdir;
-                                    weight = had(weight, color * Tr / (1.0 - prob));
-                                }
+                                dir = tdir;
+                                weight = had(weight, color * Tr / (1.0 - prob));
                             }
                         }
-                        {   // Russian roulette, src/sppm2.h:298-313
-                            double rr = max3(color);
-                            if (depth >= SPPM_KDEPTH) {
-                                rr *= ldexp(1.0, -(depth - SPPM_KDEPTH));  // std::pow(0.5, depth - MaxDepth)
-                                if (rng.next01() >= rr) break;
-                            } else
-                                rr = 1.0;
-                            weight = weight / rr;
-                        }
                     }
-                path_done:;
+                    {   // Russian roulette, src/sppm2.h:298-313
+                        double rr = max3(color);
+                        if (depth >= SPPM_KDEPTH) {
+                            rr *= ldexp(1.0, -(depth - SPPM_KDEPTH));  // std::pow(0.5, depth - MaxDepth)
+                            rng.decision();
+                            if (rng.next01() >= rr) break;
+                        } else
+                            rr = 1.0;
+                        weight = weight / rr;
+                    }
+                    if (rng.stop()) return;  // sequential-stream samplers only
                 }
-        hp.ld[index] = ld.x; hp.ld[P + index] = ld.y; hp.ld[2 * P + index] = ld.z;
+            path_done:;
+            }
+    if constexpr (COMMIT) { hp.ld[index] = ld.x; hp.ld[P + index] = ld.y; hp.ld[2 * P + index] = ld.z; }
+}
+
+// One thread per pixel, one XorShift stream per (pass, image index).
+__global__ void __launch_bounds__(256) k_eye_pass(DevScene sc, EyeParams ep, HpArrays hp, unsigned long long* __restrict__ counters)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int P = ep.W * ep.H;
+    uint32_t rays = 0;
+    if (t < P) {
+        const int index = (ep.H - t / ep.W - 1) * ep.W + t % ep.W;
+        XorShift rng = make_stream(ep.seed_eye, (uint64_t)ep.pass * (uint64_t)P + (uint64_t)index);
+        eye_pixel<XorShift, true>(sc, ep, hp, t, rng, rays);
     }
     // rays counter: one atomic per wave
+    for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off);
+    if ((threadIdx.x & 63) == 0 && rays) atomicAdd(&counters[0], (unsigned long long)rays);
+}
+
+// ---- reference-stream mode of the eye pass ----------------------------------------------------------
+// The reference draws every pixel's samples from ONE sequential stream (src/sppm2.h:621), so pixel t
+// starts where pixels 0..t-1 stopped.  Most pixels consume a number of draws that does not depend on
+// the values drawn (a diffuse first hit: the light samples only); the rest (a glass vertex, roulette
+// from depth 5 on) are "dynamic".  Three kernels: count/classify in parallel, one wavefront walks the
+// pixels in render order and resolves the dynamic ones with the real stream, then the pass itself runs
+// in parallel from the offsets found.  DYN_PIXEL marks a dynamic pixel in cnt[].
+#define DYN_PIXEL 0x80000000u
+__global__ void __launch_bounds__(256) k_eye_classify(DevScene sc, EyeParams ep, HpArrays hp)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ep.W * ep.H) return;
+    ProbeRng rng;
+    rng.count = 0; rng.dyn = false;
+    uint32_t rays = 0;
+    eye_pixel<ProbeRng, false>(sc, ep, hp, t, rng, rays);
+    ep.cnt[t] = rng.dyn ? DYN_PIXEL : (uint32_t)rng.count;
+}
+
+__global__ void __launch_bounds__(64) k_eye_offsets(DevScene sc, EyeParams ep, HpArrays hp, int32_t* __restrict__ err)
+{
+    const int lane = threadIdx.x;
+    const int P = ep.W * ep.H;
+    unsigned long long cur = 0;
+    for (int base = 0; base < P; base += 64) {
+        const int t = base + lane;
+        const uint32_t c = t < P ? ep.cnt[t] : 0u;
+        const unsigned long long dyn = __ballot(t < P && (c & DYN_PIXEL) != 0u);
+        int pos = 0;
+        while (pos < 64) {
+            const unsigned long long rest = dyn & (pos == 0 ? ~0ull : (~0ull << pos));
+            const int f = rest ? __ffsll((long long)rest) - 1 : 64;
+            // lanes [pos, f): offsets from a prefix sum of their fixed counts
+            const bool in = lane >= pos && lane < f;
+            unsigned long long incl = in ? (unsigned long long)c : 0ull;
+            for (int o = 1; o < 64; o <<= 1) { const unsigned long long y = __shfl_up(incl, o); if (lane >= o) incl += y; }
+            if (in && t < P) ep.off[t] = cur + incl - c;
+            cur += __shfl(incl, 63);
+            if (f < 64) {  // the dynamic pixel: run its paths on the real stream to see where it stops
+                unsigned long long used = 0;
+                if (lane == f) {
+                    ep.off[t] = cur;
+                    StreamRng rng; rng.u = ep.u; rng.pos = (int64_t)cur; rng.end = ep.u_len;
+                    uint32_t rays = 0;
+                    eye_pixel<StreamRng, false>(sc, ep, hp, t, rng, rays);
+                    used = (unsigned long long)rng.pos - cur;
+                    if (rng.stop()) err[4] = 1;
+                }
+                cur += __shfl(used, f);
+            }
+            pos = f + 1;
+        }
+    }
+    if (lane == 0) { ep.total[0] = cur; if ((int64_t)cur > ep.u_len) err[4] = 1; }
+}
+
+__global__ void __launch_bounds__(256) k_eye_pass_stream(DevScene sc, EyeParams ep, HpArrays hp, unsigned long long* __restrict__ counters,
+                                                        int32_t* __restrict__ err)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int P = ep.W * ep.H;
+    uint32_t rays = 0;
+    if (t < P) {
+        StreamRng rng; rng.u = ep.u; rng.pos = (int64_t)ep.off[t]; rng.end = ep.u_len;
+        eye_pixel<StreamRng, true>(sc, ep, hp, t, rng, rays);
+        // the pixel must stop exactly where the walk said the next one starts
+        const unsigned long long next = t + 1 < P ? ep.off[t + 1] : ep.total[0];
+        if ((unsigned long long)rng.pos != next) err[5] = 1;
+    }
     for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off);
     if ((threadIdx.x & 63) == 0 && rays) atomicAdd(&counters[0], (unsigned long long)rays);
 }
@@ -171,6 +265,8 @@ __global__ void __launch_bounds__(256) k_eye_pass(DevScene sc, EyeParams ep, HpA
 struct TraceParams {
     int pass; int64_t first, count, photons_per_pass; uint32_t seed_photon; double flux_scale;
     int64_t rec_cap;
+    // reference-stream mode only
+    const double* u; int64_t u_len; const uint32_t* start; uint32_t* consumed;
 };
 struct RecArrays { uint64_t* key; double* f; int64_t cap; };  // f[9][cap]
 
@@ -180,13 +276,22 @@ struct RecArrays { uint64_t* key; double* f; int64_t cap; };  // f[9][cap]
 // photon index of its wavefront's current block of 64 (blocks come from one global counter), emits it,
 // and all lanes then advance one bounce together.  Which lane traces which photon does not matter:
 // the stream is keyed by the photon index and records are ordered by key later.
-struct PhotonState { XorShift rng; d3 org, dir, flux; int depth; int64_t index; };
+//
+// MODE 0: one XorShift stream per photon.
+// Reference-stream mode (the photons of a pass share ONE sequential stream, src/sppm2.h:530):
+// MODE 2: "photon" i is a path started at stream offset i; no records, consumed[i] = draws it used.
+//         Following consumed[] from offset 0 (k_photon_chain) gives every real photon's start offset.
+// MODE 1: photon i reads the stream from start[i]; records as in mode 0.
+template <class RNG> struct PhotonState { RNG rng; d3 org, dir, flux; int depth; int64_t index; };
 struct Deposit { bool want; unsigned long long key; d3 pos, nrm, flux; };
+#define STREAM_OVER 0xFFFFFFFFu
 
-__device__ __forceinline__ void photon_emit(const DevScene& sc, const TraceParams& tp, int64_t i, PhotonState& ps)
+template <int MODE, class RNG>
+__device__ __forceinline__ void photon_emit(const DevScene& sc, const TraceParams& tp, int64_t i, PhotonState<RNG>& ps)
 {
     ps.index = i;
-    ps.rng = make_stream(tp.seed_photon, (uint64_t)tp.pass * (uint64_t)tp.photons_per_pass + (uint64_t)i);
+    if constexpr (MODE == 0) ps.rng = make_stream(tp.seed_photon, (uint64_t)tp.pass * (uint64_t)tp.photons_per_pass + (uint64_t)i);
+    else { ps.rng.u = tp.u; ps.rng.end = tp.u_len; ps.rng.pos = MODE == 1 ? (int64_t)tp.start[i] : i; }
     (void)ps.rng.next01(); (void)ps.rng.next01();  // two draws computed and discarded, src/sppm2.h:322-324
     const double r1 = 2 * SPPM_PI * ps.rng.next01();
     const double r2 = 1.0 - 2.0 * ps.rng.next01();
@@ -205,8 +310,10 @@ __device__ __forceinline__ void photon_emit(const DevScene& sc, const TraceParam
 }
 
 // one iteration of the while loop of create_photon; returns false when the path ends
-__device__ __forceinline__ bool photon_bounce(const DevScene& sc, PhotonState& ps, Deposit& dep, int32_t* __restrict__ err, uint32_t& rays)
+template <class RNG>
+__device__ __forceinline__ bool photon_bounce(const DevScene& sc, PhotonState<RNG>& ps, Deposit& dep, int32_t* __restrict__ err, uint32_t& rays)
 {
+    if (ps.rng.stop()) return false;
     if (max3(ps.flux) <= 0.0) return false;
     Hit is;
     rays++;
@@ -247,18 +354,24 @@ __device__ __forceinline__ bool photon_bounce(const DevScene& sc, PhotonState& p
     return true;
 }
 
+template <int MODE> struct TraceRng { typedef StreamRng type; };
+template <> struct TraceRng<0> { typedef XorShift type; };
+
 #define TRACE_GRAB 64
 #define REC_CHUNK 128  // record slots a wavefront reserves at a time (one atomic per chunk instead of one per record)
 #define REC_INVALID (~0ull)
+template <int MODE>
 __global__ void __launch_bounds__(256) k_photon_trace(DevScene sc, TraceParams tp, RecArrays rec, unsigned long long* __restrict__ rec_count,
                                                       unsigned long long* __restrict__ next_block, unsigned long long* __restrict__ counters,
                                                       int32_t* __restrict__ err)
 {
+    typedef typename TraceRng<MODE>::type RNG;
     const int lane = threadIdx.x & 63;
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     uint32_t rays = 0;
-    PhotonState ps;
-    ps.depth = 0; ps.index = 0; ps.org = mk(0, 0, 0); ps.dir = mk(0, 0, 1); ps.flux = mk(0, 0, 0); ps.rng.seed(1u);
+    PhotonState<RNG> ps;
+    ps.depth = 0; ps.index = 0; ps.org = mk(0, 0, 0); ps.dir = mk(0, 0, 1); ps.flux = mk(0, 0, 0);
+    if constexpr (MODE == 0) ps.rng.seed(1u); else { ps.rng.u = tp.u; ps.rng.pos = 0; ps.rng.end = tp.u_len; }
     bool active = false, exhausted = false;
     int64_t blk_lo = 0, blk_hi = 0;  // wave-uniform: the unassigned rest of this wave's current block
     int64_t chunk_lo = 0, chunk_hi = 0;  // wave-uniform: the unused rest of this wave's reserved record slots
@@ -276,13 +389,20 @@ __global__ void __launch_bounds__(256) k_photon_trace(DevScene sc, TraceParams t
                 if (blk_lo >= tp.count) { exhausted = true; blk_lo = blk_hi = 0; }
             }
             const int64_t idx = blk_lo + __popcll(need & lt_mask);
-            if (!active && idx < blk_hi) { photon_emit(sc, tp, tp.first + idx, ps); active = true; }
+            if (!active && idx < blk_hi) { photon_emit<MODE>(sc, tp, tp.first + idx, ps); active = true; }
             blk_lo = min(blk_hi, blk_lo + (int64_t)__popcll(need));
         }
         if (__ballot(active) == 0) { if (exhausted) break; else continue; }
         Deposit dep;
         dep.want = false;
-        if (active) active = photon_bounce(sc, ps, dep, err, rays);
+        if (active) {
+            active = photon_bounce(sc, ps, dep, err, rays);
+            if constexpr (MODE == 2)
+                if (!active) tp.consumed[ps.index] = ps.rng.stop() ? STREAM_OVER : (uint32_t)(ps.rng.pos - ps.index);
+            if constexpr (MODE == 1)
+                if (!active && ps.rng.stop()) err[4] = 1;
+        }
+        if constexpr (MODE == 2) continue;
         // store the records of this step: slots come from the wave's chunk, a new chunk costs one atomic
         const unsigned long long dm = __ballot(dep.want);
         if (dm != 0 && !rec_full) {
@@ -313,7 +433,33 @@ __global__ void __launch_bounds__(256) k_photon_trace(DevScene sc, TraceParams t
     }
     for (int64_t j = chunk_lo + lane; j < chunk_hi; j += 64) rec.key[j] = REC_INVALID;
     for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off);
-    if (lane == 0 && rays) atomicAdd(&counters[0], (unsigned long long)rays);
+    if (MODE != 2 && lane == 0 && rays) atomicAdd(&counters[1], (unsigned long long)rays);  // [1]: rays cast by photon tracing
+}
+
+// Reference-stream mode: photon 0 starts at offset 0, photon i+1 where photon i stopped.  One
+// wavefront follows consumed[] through an LDS window (the chain is sequential; each step is one LDS read).
+#define CHAIN_WINDOW 2048
+__global__ void __launch_bounds__(64) k_photon_chain(const uint32_t* __restrict__ consumed, int64_t u_len, int64_t count, uint32_t* __restrict__ start,
+                                                     unsigned long long* __restrict__ total, int32_t* __restrict__ err)
+{
+    __shared__ uint32_t win[CHAIN_WINDOW];
+    const int lane = threadIdx.x;
+    int64_t cur = 0, wbase = -(int64_t)CHAIN_WINDOW;
+    bool bad = false;
+    for (int64_t i = 0; i < count; i++) {
+        if (cur >= u_len) { bad = true; break; }
+        if (cur >= wbase + CHAIN_WINDOW) {
+            __syncthreads();
+            wbase = cur;
+            for (int k = lane; k < CHAIN_WINDOW; k += 64) win[k] = wbase + k < u_len ? consumed[wbase + k] : STREAM_OVER;
+            __syncthreads();
+        }
+        const uint32_t c = win[cur - wbase];
+        if (c == STREAM_OVER) { bad = true; break; }
+        if (lane == 0) start[i] = (uint32_t)cur;
+        cur += c;
+    }
+    if (lane == 0) { total[0] = (unsigned long long)cur; if (bad) err[4] = 1; }
 }
 
 // ---- hash grid over the records of a batch ----------------------------------------------------------
@@ -704,10 +850,34 @@ struct sppm_ctx {
     uint64_t* d_tap_key; int32_t* d_tap_pix; unsigned long long* d_tap_n; int64_t tap_cap;
     // timing of the gather kernel
     int timing;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
-    uint64_t gather_ns, gather_launches, gather_batches;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev, ev_trace;
+    uint64_t gather_ns, gather_launches, gather_batches, trace_ns, trace_launches;
     uint64_t photons_traced, records_total;
+    // reference-stream mode (cfg.sampler == 1): the reference's own sequential mt19937 streams
+    int sampler;
+    std::mt19937 eye_eng;               // one engine for all eye passes, src/sppm2.h:621
+    std::vector<double> eye_pending;    // drawn from eye_eng, not yet consumed by a pass
+    double *d_u_eye, *d_u_ph; int64_t u_eye_cap, u_ph_cap;
+    uint32_t *d_eye_cnt, *d_ph_start, *d_ph_consumed; int64_t ph_start_cap, ph_consumed_cap;
+    unsigned long long *d_eye_off, *d_stream_total;
+    int64_t stream_len;                 // uploaded length of the photon stream of stream_pass
+    int stream_pass;
 };
+
+// grow-only device buffer outside the allocs list (freed in sppm_destroy)
+template <typename T>
+static int grow(sppm_ctx* c, T** p, int64_t* cap, int64_t need)
+{
+    if (*cap >= need) return 0;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->trace_stream) HIPCHK(hipStreamSynchronize(c->trace_stream));
+    if (*p) hipFree(*p);
+    *p = nullptr; *cap = 0;
+    void* q = nullptr;
+    HIPCHK(hipMalloc(&q, (size_t)need * sizeof(T)));
+    *p = (T*)q; *cap = need;
+    return 0;
+}
 
 template <typename T>
 static int dev_alloc(sppm_ctx* c, T** p, size_t n, bool zero = true)
@@ -754,6 +924,7 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
     if (!(cfg->gather_radius2 > 0.0) || !(cfg->initial_radius2 > 0.0) || !(cfg->alpha > 0.0))
         return fail(SPPM_ERR_INVALID, "sppm_create: radii and alpha must be positive");
     if (cfg->update_rule != 0 && cfg->update_rule != 1) return fail(SPPM_ERR_INVALID, "sppm_create: update_rule must be 0 or 1");
+    if (cfg->sampler != 0 && cfg->sampler != 1) return fail(SPPM_ERR_INVALID, "sppm_create: sampler must be 0 (XorShift streams) or 1 (reference mt19937 stream)");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
         return fail(SPPM_ERR_HIP, "sppm_create: no HIP device (this library has no CPU path)");
@@ -777,7 +948,10 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
     c->ns = n_spheres;
     c->trace_stream = nullptr; for (int b = 0; b < 2; b++) { c->ev_traced[b] = nullptr; c->ev_free[b] = nullptr; }
     c->tap_cap = 0; c->d_tap_key = nullptr; c->d_tap_pix = nullptr; c->d_tap_n = nullptr;
-    c->timing = 0; c->gather_ns = c->gather_launches = c->gather_batches = 0; c->photons_traced = c->records_total = 0;
+    c->sampler = cfg->sampler; c->eye_eng.seed(cfg->seed_eye);
+    c->d_u_eye = c->d_u_ph = nullptr; c->u_eye_cap = c->u_ph_cap = 0; c->d_eye_cnt = nullptr; c->d_ph_start = c->d_ph_consumed = nullptr;
+    c->ph_start_cap = c->ph_consumed_cap = 0; c->d_eye_off = c->d_stream_total = nullptr; c->stream_len = 0; c->stream_pass = -1;
+    c->timing = 0; c->gather_ns = c->gather_launches = c->gather_batches = 0; c->trace_ns = c->trace_launches = 0; c->photons_traced = c->records_total = 0;
     int rc = 0;
 #define TRY(x) do { rc = (x); if (rc) { sppm_destroy(c); return rc; } } while (0)
     if (hipGetDevice(&c->device) != hipSuccess) { delete c; return fail(SPPM_ERR_HIP, "hipGetDevice failed"); }
@@ -821,6 +995,11 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
     c->cur = 0; c->rec_u = c->rec_buf[0]; c->d_rec_count = c->d_rec_count_buf[0]; c->d_trace_next = c->d_trace_next_buf[0];
     c->pre.valid = 0;
     c->prefetch = (int)env_i64("SPPM_PREFETCH", 1);
+    if (c->sampler == 1) {
+        c->prefetch = 0;  // a pass's photon stream offsets exist only once its photon pass has begun
+        TRY(dev_alloc(c, &c->d_eye_cnt, (size_t)cfg->width * cfg->height)); TRY(dev_alloc(c, &c->d_eye_off, (size_t)cfg->width * cfg->height));
+        TRY(dev_alloc(c, &c->d_stream_total, 1));
+    }
     if (hipStreamCreateWithFlags(&c->trace_stream, hipStreamNonBlocking) != hipSuccess) { sppm_destroy(c); return fail(SPPM_ERR_HIP, "creating the trace stream failed"); }
     for (int b = 0; b < 2; b++)
         if (hipEventCreateWithFlags(&c->ev_traced[b], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_free[b], hipEventDisableTiming) != hipSuccess) {
@@ -834,7 +1013,7 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
     if (c->gather_mode) nb = (uint32_t)((c->table_cap + SCAN_BLOCK) / SCAN_BLOCK * SCAN_BLOCK);
     TRY(dev_alloc(c, &c->d_cell_cnt, (size_t)nb)); TRY(dev_alloc(c, &c->d_cell_start, (size_t)nb + 1)); TRY(dev_alloc(c, &c->d_cursor, (size_t)nb));
     TRY(dev_alloc(c, &c->d_block_sum, (size_t)nb / SCAN_BLOCK + 1)); TRY(dev_alloc(c, &c->d_total, 1));
-    TRY(dev_alloc(c, &c->d_counters, 24)); TRY(dev_alloc(c, &c->d_r2max, 1)); TRY(dev_alloc(c, &c->d_err, 4));
+    TRY(dev_alloc(c, &c->d_counters, 24)); TRY(dev_alloc(c, &c->d_r2max, 1)); TRY(dev_alloc(c, &c->d_err, 8));
     TRY(dev_alloc(c, &c->d_stats, 1));
     {   // the image indices this rank owns (8x8 screen tiles dealt round-robin), in index order
         std::vector<int32_t> own;
@@ -880,7 +1059,12 @@ extern "C" int sppm_destroy(sppm_ctx* c)
     for (int b = 0; b < 2; b++) { if (c->ev_traced[b]) hipEventDestroy(c->ev_traced[b]); if (c->ev_free[b]) hipEventDestroy(c->ev_free[b]); }
     if (c->trace_stream) hipStreamDestroy(c->trace_stream);
     for (auto& e : c->ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    for (auto& e : c->ev_trace) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (void* p : c->allocs) hipFree(p);
+    if (c->d_u_eye) hipFree(c->d_u_eye);
+    if (c->d_u_ph) hipFree(c->d_u_ph);
+    if (c->d_ph_start) hipFree(c->d_ph_start);
+    if (c->d_ph_consumed) hipFree(c->d_ph_consumed);
     delete c;
     return SPPM_OK;
 }
@@ -905,14 +1089,96 @@ extern "C" int sppm_intersect(sppm_ctx* c, const double* d_rays, int64_t n, int3
     return SPPM_OK;
 }
 
+// Eye pass on the reference's sequential stream (see k_eye_classify / k_eye_offsets / k_eye_pass_stream).
+static int eye_pass_stream(sppm_ctx* c, EyeParams& ep)
+{
+    hipStream_t st = c->stream;
+    std::uniform_real_distribution<double> dist(0.0, 1.0);  // the reference's ValueSampler, src/sampler/value_sampler.h:8-15
+    const int64_t paths = (int64_t)c->P * c->cfg.samples * c->cfg.supersamples * c->cfg.supersamples;
+    int64_t need = 8 * paths + 4096;
+    ep.cnt = c->d_eye_cnt; ep.off = c->d_eye_off; ep.total = c->d_stream_total;
+    hipLaunchKernelGGL(k_eye_classify, dim3(nblk(c->P, 256)), dim3(256), 0, st, scene_of(c), ep, c->hp);
+    HIPCHK(hipGetLastError());
+    unsigned long long total = 0;
+    for (int attempt = 0;; attempt++) {
+        while ((int64_t)c->eye_pending.size() < need) c->eye_pending.push_back(dist(c->eye_eng));
+        int rc = grow(c, &c->d_u_eye, &c->u_eye_cap, need);
+        if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(c->d_u_eye, c->eye_pending.data(), (size_t)need * 8, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemsetAsync(c->d_err + 4, 0, sizeof(int32_t), st));
+        ep.u = c->d_u_eye; ep.u_len = need;
+        hipLaunchKernelGGL(k_eye_offsets, dim3(1), dim3(64), 0, st, scene_of(c), ep, c->hp, c->d_err);
+        HIPCHK(hipGetLastError());
+        int32_t short_stream = 0;
+        HIPCHK(hipMemcpyAsync(&short_stream, c->d_err + 4, sizeof short_stream, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(&total, c->d_stream_total, sizeof total, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (!short_stream) break;
+        if (attempt >= 6) return fail(SPPM_ERR_OVERFLOW, "sppm_eye_pass: the eye paths consume more of the stream than 512 draws per path");
+        need *= 2;
+    }
+    hipLaunchKernelGGL(k_eye_pass_stream, dim3(nblk(c->P, 256)), dim3(256), 0, st, scene_of(c), ep, c->hp, c->d_counters, c->d_err);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));  // the upload source shrinks below
+    c->eye_pending.erase(c->eye_pending.begin(), c->eye_pending.begin() + (ptrdiff_t)total);
+    return 0;
+}
+
+// Photon pass on the reference's sequential stream: a fresh mt19937 per pass (src/sppm2.h:530; the seed
+// is seed_photon + pass where the reference asks std::random_device), one probe path per stream offset,
+// then the chain of start offsets.  After this, k_photon_trace<1> can trace the pass's photons in parallel.
+static int prepare_photon_stream(sppm_ctx* c, int32_t pass, int64_t count)
+{
+    hipStream_t st = c->stream;
+    if (count > (1ll << 27)) return fail(SPPM_ERR_INVALID, "reference-stream mode supports at most 2^27 photons per pass");
+    std::mt19937 eng(c->cfg.seed_photon + (uint32_t)pass);
+    std::uniform_real_distribution<double> dist(0.0, 1.0);
+    std::vector<double> u;
+    int64_t len = 16 * count + 4096;
+    int rc = grow(c, &c->d_ph_start, &c->ph_start_cap, count);
+    if (rc) return rc;
+    for (int attempt = 0;; attempt++) {
+        u.reserve((size_t)len);
+        while ((int64_t)u.size() < len) u.push_back(dist(eng));
+        if ((rc = grow(c, &c->d_u_ph, &c->u_ph_cap, len))) return rc;
+        if ((rc = grow(c, &c->d_ph_consumed, &c->ph_consumed_cap, len))) return rc;
+        HIPCHK(hipMemcpyAsync(c->d_u_ph, u.data(), (size_t)len * 8, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemsetAsync(c->d_err + 4, 0, sizeof(int32_t), st));
+        HIPCHK(hipMemsetAsync(c->d_trace_next_buf[c->cur], 0, sizeof(unsigned long long), st));
+        TraceParams tp;
+        memset(&tp, 0, sizeof tp);
+        tp.pass = pass; tp.first = 0; tp.count = len; tp.photons_per_pass = c->cfg.photons_per_pass; tp.seed_photon = c->cfg.seed_photon;
+        tp.flux_scale = c->flux_scale; tp.rec_cap = 0; tp.u = c->d_u_ph; tp.u_len = len; tp.start = nullptr; tp.consumed = c->d_ph_consumed;
+        const int blocks = (int)std::min<int64_t>(nblk(len, 256), 256 * 4);
+        hipLaunchKernelGGL(k_photon_trace<2>, dim3(blocks), dim3(256), 0, st, scene_of(c), tp, c->rec_buf[c->cur], c->d_rec_count_buf[c->cur],
+                           c->d_trace_next_buf[c->cur], c->d_counters, c->d_err);
+        hipLaunchKernelGGL(k_photon_chain, dim3(1), dim3(64), 0, st, c->d_ph_consumed, len, count, c->d_ph_start, c->d_stream_total, c->d_err);
+        HIPCHK(hipGetLastError());
+        int32_t short_stream = 0;
+        HIPCHK(hipMemcpyAsync(&short_stream, c->d_err + 4, sizeof short_stream, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (!short_stream) break;
+        if (attempt >= 6) return fail(SPPM_ERR_OVERFLOW, "sppm_photon_pass: the photons consume more than 1024 draws each on average");
+        len *= 2;
+    }
+    c->stream_len = len; c->stream_pass = pass;
+    return 0;
+}
+
 extern "C" int sppm_eye_pass(sppm_ctx* c, int32_t pass)
 {
     if (!c || pass < 0) return fail(SPPM_ERR_INVALID, "sppm_eye_pass: bad argument");
     EyeParams ep;
     ep.cam = c->cam; ep.W = c->cfg.width; ep.H = c->cfg.height; ep.samples = c->cfg.samples; ep.supersamples = c->cfg.supersamples;
     ep.pass = pass; ep.seed_eye = c->cfg.seed_eye; ep.initial_r2 = c->cfg.initial_radius2; ep.double_nee = c->cfg.double_nee;
-    hipLaunchKernelGGL(k_eye_pass, dim3(nblk(c->P, 256)), dim3(256), 0, c->stream, scene_of(c), ep, c->hp, c->d_counters);
-    HIPCHK(hipGetLastError());
+    ep.u = nullptr; ep.u_len = 0; ep.cnt = nullptr; ep.off = nullptr; ep.total = nullptr;
+    if (c->sampler == 1) {
+        int rc = eye_pass_stream(c, ep);
+        if (rc) return rc;
+    } else {
+        hipLaunchKernelGGL(k_eye_pass, dim3(nblk(c->P, 256)), dim3(256), 0, c->stream, scene_of(c), ep, c->hp, c->d_counters);
+        HIPCHK(hipGetLastError());
+    }
     if (c->gather_mode && c->n_own_pix > 0) {
         // re-form the gather tiles: sort this rank's hitpoints along a Morton curve of their positions
         unsigned long long init[6] = {~0ull, ~0ull, ~0ull, 0ull, 0ull, 0ull};
@@ -941,7 +1207,16 @@ static int trace_into(sppm_ctx* c, int b, int32_t pass, int64_t first, int64_t c
     // persistent waves: enough to fill the chip (4 waves per SIMD), never more than the photons need
     HIPCHK(hipMemsetAsync(c->d_trace_next_buf[b], 0, sizeof(unsigned long long), st));
     const int trace_blocks = (int)std::min<int64_t>(nblk(count, 256), 256 * 4);
-    hipLaunchKernelGGL(k_photon_trace, dim3(trace_blocks), dim3(256), 0, st, scene_of(c), tp, c->rec_buf[b], c->d_rec_count_buf[b], c->d_trace_next_buf[b], c->d_counters, c->d_err);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (c->timing) { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventRecord(e0, st)); }
+    tp.u = nullptr; tp.u_len = 0; tp.start = nullptr; tp.consumed = nullptr;
+    if (c->sampler == 1) {
+        if (c->stream_pass != pass) return fail(SPPM_ERR_STATE, "reference-stream mode: the pass's stream offsets are made by sppm_photon_pass(pass, 0, photons)");
+        tp.u = c->d_u_ph; tp.u_len = c->stream_len; tp.start = c->d_ph_start;
+        hipLaunchKernelGGL(k_photon_trace<1>, dim3(trace_blocks), dim3(256), 0, st, scene_of(c), tp, c->rec_buf[b], c->d_rec_count_buf[b], c->d_trace_next_buf[b], c->d_counters, c->d_err);
+    } else
+        hipLaunchKernelGGL(k_photon_trace<0>, dim3(trace_blocks), dim3(256), 0, st, scene_of(c), tp, c->rec_buf[b], c->d_rec_count_buf[b], c->d_trace_next_buf[b], c->d_counters, c->d_err);
+    if (c->timing) { HIPCHK(hipEventRecord(e1, st)); c->ev_trace.push_back({e0, e1}); }
     HIPCHK(hipGetLastError());
     c->photons_traced += (uint64_t)count;
     return 0;
@@ -1254,6 +1529,11 @@ extern "C" int sppm_photon_pass(sppm_ctx* c, int32_t pass, int64_t first, int64_
     if (count == 0) return SPPM_OK;
     if (c->rec_end != c->rec_first) return fail(SPPM_ERR_STATE, "sppm_photon_pass: records of an earlier sppm_trace are still waiting for sppm_gather");
     int rc;
+    if (c->sampler == 1) {
+        if (first != 0) return fail(SPPM_ERR_INVALID, "sppm_photon_pass: reference-stream mode traces a pass from photon 0 (the stream is sequential)");
+        rc = prepare_photon_stream(c, pass, count);
+        if (rc) return rc;
+    }
     int64_t n = std::min(batch_size(c, c->photons_applied), count);
     int b;
     if (c->pre.valid && c->pre.pass == pass && c->pre.first == first && c->pre.count == n) {
@@ -1378,13 +1658,22 @@ static int resolve_events(sppm_ctx* c)
         hipEventDestroy(e.first); hipEventDestroy(e.second);
     }
     c->ev.clear();
+    for (auto& e : c->ev_trace) {
+        HIPCHK(hipEventSynchronize(e.second));
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, e.first, e.second));
+        c->trace_ns += (uint64_t)((double)ms * 1e6);
+        c->trace_launches++;
+        hipEventDestroy(e.first); hipEventDestroy(e.second);
+    }
+    c->ev_trace.clear();
     return 0;
 }
 
 extern "C" int sppm_check(sppm_ctx* c)
 {
     if (!c) return fail(SPPM_ERR_INVALID, "sppm_check: null context");
-    int32_t err[4] = {0, 0, 0, 0};
+    int32_t err[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     HIPCHK(hipStreamSynchronize(c->trace_stream));
     HIPCHK(hipMemcpyAsync(err, c->d_err, sizeof err, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -1394,6 +1683,8 @@ extern "C" int sppm_check(sppm_ctx* c)
     if (err[1]) return fail(SPPM_ERR_OVERFLOW, "a photon path exceeded 32767 bounces");
     if (err[2]) return fail(SPPM_ERR_OVERFLOW, "a query exceeded gather_max (the K cap is not implemented)");
     if (err[3]) return fail(SPPM_ERR_STATE, "a record's photon index lies outside the range declared for the batch");
+    if (err[4]) return fail(SPPM_ERR_OVERFLOW, "reference-stream mode: a path ran past the uploaded part of the stream");
+    if (err[5]) return fail(SPPM_ERR_STATE, "reference-stream mode: a pixel consumed a different number of draws than the offset walk found");
     return SPPM_OK;
 }
 
@@ -1509,17 +1800,19 @@ extern "C" int sppm_download_accepted(sppm_ctx* c, uint64_t* h_key, int32_t* h_p
     return SPPM_OK;
 }
 
-extern "C" int sppm_counters(sppm_ctx* c, uint64_t h_out[12])
+extern "C" int sppm_counters(sppm_ctx* c, uint64_t h_out[16])
 {
     if (!c || !h_out) return fail(SPPM_ERR_INVALID, "sppm_counters: null argument");
     unsigned long long d[8];
+    HIPCHK(hipStreamSynchronize(c->trace_stream));
     HIPCHK(hipMemcpyAsync(d, c->d_counters, sizeof d, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     int rc = resolve_events(c);
     if (rc) return rc;
-    h_out[0] = d[0]; h_out[1] = c->photons_traced; h_out[2] = c->records_total; h_out[3] = d[3]; h_out[4] = d[4];
+    h_out[0] = d[0] + d[1]; h_out[1] = c->photons_traced; h_out[2] = c->records_total; h_out[3] = d[3]; h_out[4] = d[4];
     h_out[5] = c->gather_batches; h_out[6] = c->gather_ns; h_out[7] = c->gather_launches;
-    h_out[8] = d[5]; h_out[9] = d[6]; h_out[10] = d[7]; h_out[11] = 0;
+    h_out[8] = d[5]; h_out[9] = d[6]; h_out[10] = d[7]; h_out[11] = c->trace_ns; h_out[12] = c->trace_launches; h_out[13] = d[1];
+    h_out[14] = h_out[15] = 0;
     return SPPM_OK;
 }
 

@@ -27,7 +27,7 @@ def _sphere_array(table):
 def make_config(width, height, *, samples=1, supersamples=1, camera_position=scene.CAMERA_POSITION, camera_dir=None,
                 camera_up=scene.CAMERA_UP, screen_height=scene.SCREEN_HEIGHT, screen_dist=scene.SCREEN_DIST, alpha=0.7,
                 initial_radius2=25.0, gather_radius2=25.0, gather_max=1 << 40, update_rule=0, double_nee=1,
-                seed_eye=1000, seed_photon=2000, photons_per_pass=0, tile_first=0, tile_stride=0):
+                seed_eye=1000, seed_photon=2000, photons_per_pass=0, tile_first=0, tile_stride=0, sampler=0):
     cfg = capi.SppmConfig()
     cfg.width, cfg.height, cfg.samples, cfg.supersamples = width, height, samples, supersamples
     cfg.camera_position[:] = camera_position
@@ -40,6 +40,7 @@ def make_config(width, height, *, samples=1, supersamples=1, camera_position=sce
     cfg.seed_eye, cfg.seed_photon = seed_eye, seed_photon
     cfg.photons_per_pass = photons_per_pass
     cfg.tile_first, cfg.tile_stride = tile_first, tile_stride
+    cfg.sampler = sampler  # 0: XorShift streams; 1: the reference's sequential mt19937 streams
     return cfg
 
 
@@ -164,10 +165,10 @@ class SppmContext:
         return key, pix
 
     def counters(self):
-        out = np.zeros(12, np.uint64)
+        out = np.zeros(16, np.uint64)
         capi.check(self.L.sppm_counters(self.h, out.ctypes.data))
         names = ("rays", "photons", "records", "candidates", "updates", "gather_batches", "gather_ns", "gather_launches",
-                 "selected", "rounds", "tile_launches", "reserved")
+                 "selected", "rounds", "tile_launches", "trace_ns", "trace_launches", "photon_rays")
         return {k: int(v) for k, v in zip(names, out)}
 
     def set_timing(self, on=True):
