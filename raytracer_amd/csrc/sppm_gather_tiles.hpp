@@ -284,6 +284,7 @@ __global__ void __launch_bounds__(256) k_gather_tiles(HpArrays hp, DevScene sc, 
 {
     __shared__ unsigned long long s_key[4][64];
     __shared__ uint32_t s_rec[4][64];
+    __shared__ double s_row[4][64][10];  // the round's candidates in key order: position, geometric normal, flux, key
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const unsigned int item_i = item_base + blockIdx.x * 4 + wv;
     if (item_i >= (unsigned int)tp.n_owned + *n_items) return;
@@ -317,7 +318,7 @@ __global__ void __launch_bounds__(256) k_gather_tiles(HpArrays hp, DevScene sc, 
     const int64_t cap = rec.cap;
     unsigned int c_cand = 0, c_sel = 0, c_acc = 0, c_round = 0;  // wave-uniform tallies except c_acc (per lane)
     unsigned long long c_pairs = 0;
-    unsigned long long st_scan = 0, st_rank = 0, st_apply = 0;   // diagnostic build only (STAMPS)
+    unsigned long long st_scan = 0, st_rank = 0, st_apply = 0, st_walk = 0, c_walk = 0;   // diagnostic build only (STAMPS)
 #define TSTAMP() (STAMPS ? (unsigned long long)__builtin_amdgcn_s_memtime() : 0ull)
 
     // A tile is 64 consecutive hitpoints of the Morton order, which is compact except where the curve
@@ -410,7 +411,7 @@ __global__ void __launch_bounds__(256) k_gather_tiles(HpArrays hp, DevScene sc, 
                 c_sel += (unsigned int)sel_n;
                 c_pairs += (unsigned long long)sel_n * n_inc;  // (record, hitpoint) pairs whose distance test runs
                 c_round++;
-                // ---- one candidate per lane: load it, rank it by key
+                // ---- one candidate per lane: load it, rank it by key, store it in LDS at its rank
                 const bool own = lane < sel_n;
                 unsigned long long mykey = ~0ull;
                 d3 q = mk(0, 0, 0), gn = mk(0, 0, 0), pf = mk(0, 0, 0);
@@ -423,23 +424,37 @@ __global__ void __launch_bounds__(256) k_gather_tiles(HpArrays hp, DevScene sc, 
                 }
                 int rank = 0;
                 for (int jj = 0; jj < sel_n; jj++) rank += (s_key[wv][jj] < mykey) ? 1 : 0;
+                if (own) {
+                    double* row = s_row[wv][rank];  // q, g0, key, flux
+                    row[0] = q.x; row[1] = q.y; row[2] = q.z; row[3] = gn.x; row[4] = gn.y; row[5] = gn.z;
+                    row[6] = __longlong_as_double((long long)mykey); row[7] = pf.x; row[8] = pf.y; row[9] = pf.z;
+                }
                 __builtin_amdgcn_wave_barrier();
                 const unsigned long long ts2 = TSTAMP();
                 st_rank += ts2 - ts1;
-                // ---- apply in key order
-                for (int t = 0; t < sel_n; t++) {
-                    const unsigned long long ms = __ballot(own && rank == t);
-                    const int src = __ffsll((long long)ms) - 1;
-                    const d3 qq = mk(rl_d(q.x, src), rl_d(q.y, src), rl_d(q.z, src));
+                // ---- phase 1, all lanes against candidate t (an LDS broadcast): every test that does not
+                // depend on the radius as it shrinks.  Bit t of `todo` = lane may accept candidate t.
+                // The row of candidate t+1 is read while candidate t is tested.
+                unsigned long long todo = 0;
+                const int sel_u = __builtin_amdgcn_readfirstlane(sel_n);
+                double n0, n1, n2, n3, n4, n5, n6;
+                {
+                    const double* row = s_row[wv][0];
+                    n0 = row[0]; n1 = row[1]; n2 = row[2]; n3 = row[3]; n4 = row[4]; n5 = row[5]; n6 = row[6];
+                }
+                for (int t = 0; t < sel_u; t++) {
+                    const d3 qq = mk(n0, n1, n2), g0 = mk(n3, n4, n5);
+                    const unsigned int klow = (unsigned int)__double_as_longlong(n6);
+                    {
+                        const double* row = s_row[wv][t + 1 < sel_u ? t + 1 : t];
+                        n0 = row[0]; n1 = row[1]; n2 = row[2]; n3 = row[3]; n4 = row[4]; n5 = row[5]; n6 = row[6];
+                    }
                     const d3 dir = hpos - qq;
                     const double d2 = len2(dir);
-                    bool ok = inc && (d2 < tp.gather_r2) && (d2 <= r2);
+                    // r2 only shrinks: d2 <= r2 here accepts a superset of what phase 2 accepts
+                    bool ok = inc && (d2 < tp.gather_r2) && (d2 <= r2) && (dot(hn, g0) > 1e-3);
                     if (__ballot(ok) == 0) continue;
-                    const d3 g0 = mk(rl_d(gn.x, src), rl_d(gn.y, src), rl_d(gn.z, src));
-                    ok = ok && (dot(hn, g0) > 1e-3);
-                    if (__ballot(ok) == 0) continue;
-                    const int klow = __builtin_amdgcn_readlane((int)(unsigned int)mykey, src);
-                    const d3 on = (klow & 1) ? g0 * -1.0 : g0;
+                    const d3 on = (klow & 1u) ? g0 * -1.0 : g0;
                     {   // flatness filter |dot(on, dir/sqrt(d2))| <= thr, decided without the square root
                         // and the three divisions unless the squared form is within rounding of the bound
                         const double s1 = dot(on, dir);
@@ -456,31 +471,48 @@ __global__ void __launch_bounds__(256) k_gather_tiles(HpArrays hp, DevScene sc, 
                         }
                         ok = ok && flat;
                     }
-                    if (__ballot(ok) == 0) continue;
-                    const d3 ff = mk(rl_d(pf.x, src), rl_d(pf.y, src), rl_d(pf.z, src));
-                    if (ok) {
-                        if (tp.rule == 0) {  // src/sppm2.h:397-419
-                            double g;
-                            if (n != 0) g = (n * tp.alpha + tp.alpha) / (n * tp.alpha + 1.0);
-                            else g = 1;
-                            r2 = r2 * g;
-                            n++;
-                            acc = (acc + had(hw, had(hcol, ff)) / SPPM_PI) * g;
-                        } else {             // src/stochastic_ppm.h:449-454
-                            const d3 f = hcol / SPPM_PI;
-                            acc = acc + had(ff, f);
-                            madd++;
+                    if (ok) todo |= 1ull << t;
+                }
+                // ---- phase 2, every lane walks ITS OWN candidates in key order: only accepted pairs cost
+                // an update, and the trip count is the longest list of the wave, not the candidate count.
+                // A lane with nothing to do adds zero flux and scales by one, which changes nothing.
+                const unsigned long long ts3 = TSTAMP();
+                while (__ballot(todo != 0ull) != 0ull) {
+                    if (STAMPS) c_walk++;
+                    const bool has = todo != 0ull;
+                    const int t = has ? __ffsll((long long)todo) - 1 : 0;
+                    todo &= todo - 1ull;   // 0 stays 0
+                    const double* row = s_row[wv][t];
+                    const d3 dir = hpos - mk(row[0], row[1], row[2]);
+                    const d3 ff = mk(row[7], row[8], row[9]);
+                    const double d2 = len2(dir);
+                    const bool take = has && (d2 <= r2);
+                    if (tp.rule == 0) {  // src/sppm2.h:397-419
+                        if (__ballot(take) != 0ull) {
+                            const double na = n * tp.alpha;
+                            double g = (na + tp.alpha) / (na + 1.0);
+                            if (n == 0) g = 1;
+                            const d3 add = had(hw, had(hcol, ff)) / SPPM_PI;
+                            if (take) {
+                                r2 = r2 * g;
+                                n++;
+                                acc = (acc + add) * g;
+                                c_acc++;
+                            }
                         }
+                    } else if (take) {   // src/stochastic_ppm.h:449-454
+                        const d3 f = hcol / SPPM_PI;
+                        acc = acc + had(ff, f);
+                        madd++;
                         c_acc++;
-                        if (tp.tap_cap > 0) {
-                            const unsigned long long kfull = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(mykey >> 32), src) << 32) |
-                                                             (unsigned int)klow;
-                            const unsigned long long slot = atomicAdd(tp.tap_n, 1ull);
-                            if ((int64_t)slot < tp.tap_cap) { tp.tap_key[slot] = kfull; tp.tap_pix[slot] = p; }
-                        }
+                    }
+                    if (tp.tap_cap > 0 && take) {
+                        const unsigned long long slot = atomicAdd(tp.tap_n, 1ull);
+                        if ((int64_t)slot < tp.tap_cap) { tp.tap_key[slot] = (unsigned long long)__double_as_longlong(row[6]); tp.tap_pix[slot] = p; }
                     }
                 }
-                st_apply += TSTAMP() - ts2;
+                __builtin_amdgcn_wave_barrier();
+                if (STAMPS) { const unsigned long long ts4 = TSTAMP(); st_apply += ts4 - ts2; st_walk += ts4 - ts3; }
             }
             klo = khi;
             khi = kend;
@@ -510,7 +542,7 @@ __global__ void __launch_bounds__(256) k_gather_tiles(HpArrays hp, DevScene sc, 
         const unsigned long long cyc = (unsigned long long)(__builtin_amdgcn_s_memtime() - t_start);
         atomicMax(&counters[11], cyc); atomicAdd(&counters[12], cyc);
         atomicMax(&counters[13], ((unsigned long long)c_sel << 24) | (unsigned long long)k);
-        if (STAMPS) { atomicAdd(&counters[16], st_scan); atomicAdd(&counters[17], st_rank); atomicAdd(&counters[18], st_apply); }
+        if (STAMPS) { atomicAdd(&counters[16], st_scan); atomicAdd(&counters[17], st_rank); atomicAdd(&counters[18], st_apply); atomicAdd(&counters[19], st_walk); atomicAdd(&counters[20], c_walk); }
     }
 #undef TSTAMP
 }

@@ -1461,8 +1461,9 @@ static int gather_tiles(sppm_ctx* c)
                 (double)(cnt1[5] - cnt0[5]) / std::max(1.0, tiles_run * S), (double)(cnt1[14]) / std::max(1.0, (double)(cnt1[5] - cnt0[5])),
                 (long long)c->slab_B);
     if (dbg && getenv("SPPM_STAMPS"))
-        fprintf(stderr, "[sppm]   stamps (share of item cycles): scan %.1f%% rank+load %.1f%% apply %.1f%%\n", 100.0 * cnt1[16] / std::max(1.0, (double)cnt1[12]),
-                100.0 * cnt1[17] / std::max(1.0, (double)cnt1[12]), 100.0 * cnt1[18] / std::max(1.0, (double)cnt1[12]));
+        fprintf(stderr, "[sppm]   stamps (share of item cycles): scan %.1f%% rank+load %.1f%% apply %.1f%% (of which walk %.1f%%); walk trips per round %.2f, updates per round %.1f\n", 100.0 * cnt1[16] / std::max(1.0, (double)cnt1[12]),
+                100.0 * cnt1[17] / std::max(1.0, (double)cnt1[12]), 100.0 * cnt1[18] / std::max(1.0, (double)cnt1[12]), 100.0 * cnt1[19] / std::max(1.0, (double)cnt1[12]),
+                (double)cnt1[20] / std::max(1.0, (double)(cnt1[6] - cnt0[6])), (double)(cnt1[4] - cnt0[4]) / std::max(1.0, (double)(cnt1[6] - cnt0[6])));
     if (dbg) {
         const int hk = (int)(cnt1[13] & 0xffffff);
         std::vector<int32_t> ord(64), obj(64);
