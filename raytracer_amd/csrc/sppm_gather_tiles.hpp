@@ -93,9 +93,17 @@ __global__ void k_hp_bbox(HpArrays hp, const int32_t* __restrict__ pix, int n, u
         if (!hp.valid[p]) continue;
         for (int a = 0; a < 3; a++) { const double v = hp.pos[a * P + p]; lo[a] = fmin(lo[a], v); hi[a] = fmax(hi[a], v); }
     }
+    __shared__ double s_lo[4][3], s_hi[4][3];
     for (int a = 0; a < 3; a++) {
         for (int off = 32; off > 0; off >>= 1) { lo[a] = fmin(lo[a], __shfl_xor(lo[a], off)); hi[a] = fmax(hi[a], __shfl_xor(hi[a], off)); }
-        if ((threadIdx.x & 63) == 0 && lo[a] <= hi[a]) { atomicMin(&bb[a], ord_d(lo[a])); atomicMax(&bb[3 + a], ord_d(hi[a])); }
+        if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6][a] = lo[a]; s_hi[threadIdx.x >> 6][a] = hi[a]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {  // one pair of atomics per block and axis (launched with 256 threads)
+        const int a = threadIdx.x;
+        const double l = fmin(fmin(s_lo[0][a], s_lo[1][a]), fmin(s_lo[2][a], s_lo[3][a]));
+        const double h = fmax(fmax(s_hi[0][a], s_hi[1][a]), fmax(s_hi[2][a], s_hi[3][a]));
+        if (l <= h) { atomicMin(&bb[a], ord_d(l)); atomicMax(&bb[3 + a], ord_d(h)); }
     }
 }
 __device__ __forceinline__ unsigned long long spread3(unsigned long long x)  // 21 bits -> every third bit
@@ -108,20 +116,23 @@ __device__ __forceinline__ unsigned long long spread3(unsigned long long x)  // 
     x = (x | (x << 2)) & 0x1249249249249249ull;
     return x;
 }
-// 48-bit Morton code (16 bits per axis over the bounding box); invalid hitpoints sort last
+// Morton code, MORTON_BITS bits per axis over the bounding box (ties keep pixel order: the sort is stable);
+// invalid hitpoints sort last
+#define MORTON_BITS 12
+#define MORTON_MAX ((double)((1 << MORTON_BITS) - 1))
 __global__ void k_hp_sortkeys(HpArrays hp, const int32_t* __restrict__ pix, int n, const unsigned long long* __restrict__ bb,
                               unsigned long long* __restrict__ keys)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int p = pix[i], P = hp.P;
-    if (!hp.valid[p]) { keys[i] = (1ull << 48); return; }
+    if (!hp.valid[p]) { keys[i] = (1ull << (3 * MORTON_BITS)); return; }
     unsigned long long code = 0;
     for (int a = 0; a < 3; a++) {
         const double lo = undo_ord_d(bb[a]), hi = undo_ord_d(bb[3 + a]);
         const double ext = hi - lo;
-        double f = ext > 0.0 ? (hp.pos[a * P + p] - lo) / ext * 65535.0 : 0.0;
-        f = f < 0.0 ? 0.0 : (f > 65535.0 ? 65535.0 : f);
+        double f = ext > 0.0 ? (hp.pos[a * P + p] - lo) / ext * MORTON_MAX : 0.0;
+        f = f < 0.0 ? 0.0 : (f > MORTON_MAX ? MORTON_MAX : f);
         code |= spread3((unsigned long long)f) << a;
     }
     keys[i] = code;
@@ -208,6 +219,35 @@ __global__ void k_cell_totals(const uint32_t* __restrict__ cell_cnt, int ncells,
     cell_tot[c] = t;
 }
 
+// Summed-area table over the per-cell totals, in place: after the three passes cell (x, y, z) holds the
+// records of all cells (<= x, <= y, <= z), so the plan gets a region's record count from 8 corners.
+__global__ void k_sat_axis(uint32_t* __restrict__ t, int nx, int ny, int nz, int axis)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n_lines = axis == 0 ? ny * nz : (axis == 1 ? nx * nz : nx * ny);
+    if (i >= n_lines) return;
+    size_t base, stride; int len;
+    if (axis == 0) { base = (size_t)i * nx; stride = 1; len = nx; }                                    // i = z*ny + y
+    else if (axis == 1) { base = (size_t)(i / nx) * nx * ny + (size_t)(i % nx); stride = (size_t)nx; len = ny; }  // i = z*nx + x
+    else { base = (size_t)i; stride = (size_t)nx * ny; len = nz; }                                     // i = y*nx + x
+    uint32_t run = 0;
+    for (int k = 0; k < len; k++) { run += t[base + k * stride]; t[base + k * stride] = run; }
+}
+// records in cells [x0..x1] x [y0..y1] x [z0..z1]; lanes 0..7 fetch one corner each (wave-uniform result)
+__device__ __forceinline__ unsigned int sat_box(const uint32_t* __restrict__ sat, int nx, int ny, int x0, int x1, int y0, int y1, int z0, int z1, int lane)
+{
+    int v = 0;
+    if (lane < 8) {
+        const int x = (lane & 1) ? x1 : x0 - 1, y = (lane & 2) ? y1 : y0 - 1, z = (lane & 4) ? z1 : z0 - 1;
+        if (x >= 0 && y >= 0 && z >= 0) {
+            const int val = (int)sat[((size_t)z * ny + y) * nx + x];
+            v = (__popc(lane & 7) & 1) ? val : -val;   // + for an odd number of upper corners, - otherwise (3 -> +, 2 -> -, 1 -> +, 0 -> -)
+        }
+    }
+    for (int off = 4; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return (unsigned int)__builtin_amdgcn_readfirstlane(v);
+}
+
 // ---- work items: (tile, lane range) ---------------------------------------------------------------------
 // Record density is very uneven (caustics, the gap between the light and the ceiling hold a few
 // percent of all records in a few square units).  A tile there has ~100x the average work, and a tile
@@ -254,15 +294,7 @@ __global__ void __launch_bounds__(256) k_tile_plan(HpArrays hp, const uint32_t* 
         const int cx0 = grid_coord(wave_min_d(in ? x : BIG) - rm, tp.g.ox, tp.g.inv_c, tp.g.nx), cx1 = grid_coord(wave_max_d(in ? x : -BIG) + rm, tp.g.ox, tp.g.inv_c, tp.g.nx);
         const int cy0 = grid_coord(wave_min_d(in ? y : BIG) - rm, tp.g.oy, tp.g.inv_c, tp.g.ny), cy1 = grid_coord(wave_max_d(in ? y : -BIG) + rm, tp.g.oy, tp.g.inv_c, tp.g.ny);
         const int cz0 = grid_coord(wave_min_d(in ? z : BIG) - rm, tp.g.oz, tp.g.inv_c, tp.g.nz), cz1 = grid_coord(wave_max_d(in ? z : -BIG) + rm, tp.g.oz, tp.g.inv_c, tp.g.nz);
-        const int kx = cx1 - cx0 + 1, ky = cy1 - cy0 + 1, kz = cz1 - cz0 + 1;
-        const int Ktot = kx * ky * kz;
-        unsigned int sum = 0;
-        for (int q = lane; q < Ktot; q += 64) {
-            const int ix = cx0 + q % kx, iy = cy0 + (q / kx) % ky, iz = cz0 + q / (kx * ky);
-            sum += cell_tot[(iz * tp.g.ny + iy) * tp.g.nx + ix];
-        }
-        for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
-        sum = (unsigned int)__builtin_amdgcn_readfirstlane((int)sum);
+        const unsigned int sum = sat_box(cell_tot, tp.g.nx, tp.g.ny, cx0, cx1, cy0, cy1, cz0, cz1, lane);
         if (first) { if (lane == 0) est[k] = sum; first = false; }
         if (sum <= threshold || len == 1) {
             if (lane == 0) {

@@ -940,7 +940,7 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
     c->table_cap = env_i64("SPPM_TABLE_CAP", 1ll << 24);
     if (c->table_cap < 4096) c->table_cap = 4096;
     if (c->table_cap > (1ll << 24)) c->table_cap = 1ll << 24;
-    c->cell_factor = 0.5;
+    c->cell_factor = 0.35;
     { const char* e = getenv("SPPM_CELL_FACTOR"); if (e && *e) c->cell_factor = atof(e); }
     c->slab_B = env_i64("SPPM_SLAB_PHOTONS", 1024);
     c->rec_first = c->rec_end = 0;
@@ -1037,7 +1037,7 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
         { const char* e = getenv("SPPM_SPLIT_FACTOR"); if (e && *e) c->split_factor = atof(e); }
         if (c->n_own_pix > 0) {
             if (rocprim::radix_sort_pairs(nullptr, c->sort_tmp_bytes, c->d_hp_keys, c->d_hp_keys_out, c->d_own_pix, c->d_order,
-                                          (size_t)c->n_own_pix, 0, 49, c->stream) != hipSuccess) {
+                                          (size_t)c->n_own_pix, 0, 3 * MORTON_BITS + 1, c->stream) != hipSuccess) {
                 sppm_destroy(c); return fail(SPPM_ERR_HIP, "sizing the hitpoint sort failed");
             }
             char* tmp = nullptr;
@@ -1183,11 +1183,11 @@ extern "C" int sppm_eye_pass(sppm_ctx* c, int32_t pass)
         // re-form the gather tiles: sort this rank's hitpoints along a Morton curve of their positions
         unsigned long long init[6] = {~0ull, ~0ull, ~0ull, 0ull, 0ull, 0ull};
         HIPCHK(hipMemcpyAsync(c->d_hp_bb, init, sizeof init, hipMemcpyHostToDevice, c->stream));
-        hipLaunchKernelGGL(k_hp_bbox, dim3(std::min(nblk(c->n_own_pix, 256), 1024)), dim3(256), 0, c->stream, c->hp, c->d_own_pix, c->n_own_pix, c->d_hp_bb);
+        hipLaunchKernelGGL(k_hp_bbox, dim3(std::min(nblk(c->n_own_pix, 256), 512)), dim3(256), 0, c->stream, c->hp, c->d_own_pix, c->n_own_pix, c->d_hp_bb);
         hipLaunchKernelGGL(k_hp_sortkeys, dim3(nblk(c->n_own_pix, 256)), dim3(256), 0, c->stream, c->hp, c->d_own_pix, c->n_own_pix, c->d_hp_bb, c->d_hp_keys);
         HIPCHK(hipGetLastError());
         HIPCHK(rocprim::radix_sort_pairs(c->d_sort_tmp, c->sort_tmp_bytes, c->d_hp_keys, c->d_hp_keys_out, c->d_own_pix, c->d_order,
-                                         (size_t)c->n_own_pix, 0, 49, c->stream));
+                                         (size_t)c->n_own_pix, 0, 3 * MORTON_BITS + 1, c->stream));
         c->order_valid = 1;
     }
     return SPPM_OK;
@@ -1374,8 +1374,9 @@ static int gather_tiles(sppm_ctx* c)
     if (hs.live_tiles == 0) return finish_batch(c);
     // median of the tiles' region extents (upper edge of the log2 bin)
     int med = 0;
-    { unsigned int acc = 0; for (int e = 0; e < 64; e++) { acc += hs.hist[e]; if (2 * acc >= hs.live_tiles) { med = e; break; } } }
-    double cell = std::ldexp(1.0, med - 32) * c->cell_factor;
+    double med_frac = 1.0;  // where inside its bin the median falls (bins are octaves, so the cell size moves smoothly from pass to pass)
+    { unsigned int acc = 0; for (int e = 0; e < 64; e++) { acc += hs.hist[e]; if (2 * acc >= hs.live_tiles) { med = e; med_frac = hs.hist[e] ? 1.0 - (double)(acc - (hs.live_tiles + 1) / 2) / (double)hs.hist[e] : 1.0; break; } } }
+    double cell = std::ldexp(1.0, med - 33) * std::exp2(med_frac) * c->cell_factor;
     double lo[3], hi[3];
     // grid box: the hitpoints' bounding box (made by the eye pass) grown by the largest search radius
     const double rgrow = std::sqrt(c->cfg.gather_radius2) * (1.0 + 1e-9) + 1e-9;
@@ -1406,12 +1407,15 @@ static int gather_tiles(sppm_ctx* c)
     hipLaunchKernelGGL(k_grid_scatter, dim3(2048), dim3(256), 0, st, c->rec_u, c->rec_s, c->d_rec_count, c->d_rec_bucket, c->d_cursor);
     // --- work items: cut tiles whose region holds far more records than the average tile's.  The
     // threshold comes from the previous batch's mean (scaled by the photon count); the first batch is not cut.
-    HIPCHK(hipMemsetAsync(c->d_n_items, 0, sizeof(unsigned int), st));
     if (c->est_valid && c->est_range > 0) c->est_per_photon = (double)hs.est_sum / (double)hs.live_tiles / (double)c->est_range;
     const double mean_est = c->est_per_photon * (double)range;
     const double thr_d = c->est_per_photon > 0.0 ? std::max(256.0, mean_est * c->split_factor) : 4.0e9;
     const uint32_t split_thr = (uint32_t)std::min(4.0e9, thr_d);
+    HIPCHK(hipMemsetAsync(c->d_n_items, 0, sizeof(unsigned int), st));
     hipLaunchKernelGGL(k_cell_totals, dim3(nblk(g.ncells, 256)), dim3(256), 0, st, c->d_cell_cnt, g.ncells, g.S, c->d_cell_tot);
+    hipLaunchKernelGGL(k_sat_axis, dim3(nblk(g.ny * g.nz, 64)), dim3(64), 0, st, c->d_cell_tot, g.nx, g.ny, g.nz, 0);
+    hipLaunchKernelGGL(k_sat_axis, dim3(nblk(g.nx * g.nz, 64)), dim3(64), 0, st, c->d_cell_tot, g.nx, g.ny, g.nz, 1);
+    hipLaunchKernelGGL(k_sat_axis, dim3(nblk(g.nx * g.ny, 64)), dim3(64), 0, st, c->d_cell_tot, g.nx, g.ny, g.nz, 2);
     hipLaunchKernelGGL(k_tile_plan, dim3(nblk(c->n_owned, 4)), dim3(256), 0, st, c->hp, c->d_cell_tot, tp, split_thr, c->d_items, c->d_n_items, c->d_est);
     c->est_valid = 1; c->est_range = range;
     // the gather grid must cover n_owned own slots + the extra pieces; their count is known only on the
