@@ -97,21 +97,24 @@ __device__ __forceinline__ XorShift make_stream(uint32_t base, uint64_t key)
 struct Hit { double distance; d3 position, normal; int object_id; };
 
 // edupt::intersect_scene, src/scene.h:53-76, over Sphere::intersect, src/sphere.h:31-56.
-// The sphere index is wave-uniform, so the sphere fields come through scalar loads.
+// The kernels stage the sphere table in LDS first (STAGE_SCENE), so the per-sphere fields are LDS
+// broadcasts, and the body is branch-free so that the independent per-sphere chains (the square root
+// above all) overlap.  Same decisions as the reference's early-outs: a sphere counts when
+// !(D4 < 0) and !(t1 < eps && t2 < eps), and the first sphere with the smallest t wins.
 __device__ __forceinline__ bool intersect_scene(const sppm_sphere* __restrict__ sp, int ns, d3 org, d3 dir, Hit& h)
 {
     double best = SPPM_INF;
     int id = -1;
+#pragma unroll 3
     for (int i = 0; i < ns; i++) {
         const d3 p_o = ld3(sp[i].position) - org;
         const double b = dot(p_o, dir);
         const double D4 = b * b - dot(p_o, p_o) + sp[i].radius * sp[i].radius;
-        if (D4 < 0.0) continue;
-        const double sq = sqrt(D4);
+        const double sq = sqrt(D4);  // NaN for D4 < 0: every comparison below is then false
         const double t1 = b - sq, t2 = b + sq;
-        if (t1 < SPPM_EPS && t2 < SPPM_EPS) continue;
+        const bool counts = !(D4 < 0.0) && !(t1 < SPPM_EPS && t2 < SPPM_EPS);
         const double t = (t1 > SPPM_EPS) ? t1 : t2;
-        if (t < best) { best = t; id = i; }
+        if (counts && t < best) { best = t; id = i; }
     }
     h.distance = best;
     h.object_id = id;
@@ -120,6 +123,15 @@ __device__ __forceinline__ bool intersect_scene(const sppm_sphere* __restrict__ 
     h.normal = normalize(h.position - ld3(sp[id].position));  // sphere.h:54
     return true;
 }
+
+// Copies the sphere table (88-byte rows = 11 doubles) into dynamic LDS and points `sc` at the copy.
+// Every thread of the block must reach it; launch with sc.ns * sizeof(sppm_sphere) bytes of dynamic LDS.
+#define SPPM_MAX_SPHERES 512
+#define STAGE_SCENE(sc)                                                                                              \
+    extern __shared__ __align__(16) double s_scene_dyn[];                                                             \
+    for (int i_ = threadIdx.x; i_ < (sc).ns * 11; i_ += blockDim.x) s_scene_dyn[i_] = ((const double*)(sc).sp)[i_];   \
+    __syncthreads();                                                                                                  \
+    (sc).sp = (const sppm_sphere*)s_scene_dyn
 
 // edupt::PinholeCamera, src/cameras.h:34-64
 struct Camera { d3 pos, sx, sy, center; double w, h, ss; };

@@ -38,6 +38,7 @@ struct TileParams {
     int n_pix, n_owned;    // entries of order[]; virtual tiles = ceil(n_pix / 64)
     double cluster_d;      // lanes farther than this (max norm) from a tile's seed lane are replayed separately
     uint64_t* tap_key; int32_t* tap_pix; unsigned long long* tap_n; int64_t tap_cap;
+    unsigned long long* item_times;  // diagnostic (SPPM_ITEM_TIMES): start/end clock of every work item
 };
 
 __device__ __forceinline__ double rl_d(double v, int lane)
@@ -260,8 +261,12 @@ __device__ __forceinline__ uint32_t pack_item(int tile, int lane0, int lanes) { 
 
 // One wavefront per tile: count the records in the cells of the tile's region; if that exceeds the
 // threshold, halve the lane range and look at each half's own (smaller) region, down to single lanes.
+// Tile k writes its pieces to raw[k*64 ..] as (record estimate << 32 | item) and their number to
+// n_pieces[k]: no shared counters here.  Cost class of a piece: c = floor(log2(estimate | 1)).
+#define ITEM_CLASSES 32
+__device__ __forceinline__ int item_class(unsigned int est) { return 31 - __clz((int)(est | 1u)); }
 __global__ void __launch_bounds__(256) k_tile_plan(HpArrays hp, const uint32_t* __restrict__ cell_tot, TileParams tp, uint32_t threshold,
-                                                   uint32_t* __restrict__ items, unsigned int* __restrict__ n_extra,
+                                                   unsigned long long* __restrict__ raw, uint8_t* __restrict__ n_pieces,
                                                    uint32_t* __restrict__ est)
 {
     __shared__ uint32_t s_stack[4][16];
@@ -273,15 +278,15 @@ __global__ void __launch_bounds__(256) k_tile_plan(HpArrays hp, const uint32_t* 
     const int p = slot < tp.n_pix ? tp.order[slot] : 0;
     bool live = slot < tp.n_pix;
     if (live) live = hp.valid[p] != 0;
-    if (__ballot(live) == 0) { if (lane == 0) { items[k] = 0xFFFFFFFFu; est[k] = 0; } return; }
+    if (__ballot(live) == 0) { if (lane == 0) { est[k] = 0; n_pieces[k] = 0; } return; }  // a tile without live hitpoints: no item
     const double BIG = 1e300;
     const double x = live ? hp.pos[p] : 0.0, y = live ? hp.pos[P + p] : 0.0, z = live ? hp.pos[2 * P + p] : 0.0;
     const double rr = live ? sqrt(fmin(hp.r2[p], tp.gather_r2)) * (1.0 + 1e-9) + 1e-9 : 0.0;
     int sp = 0;
-    bool slot_used = false;  // items[k] is this tile's own slot; further pieces go behind n_owned
     if (lane == 0) s_stack[wv][0] = (0u << 8) | 64u;  // (first lane, lanes)
     sp = 1;
     bool first = true;
+    int n_out = 0;
     while (sp > 0) {
         __builtin_amdgcn_wave_barrier();
         const uint32_t top = s_stack[wv][sp - 1];
@@ -297,38 +302,88 @@ __global__ void __launch_bounds__(256) k_tile_plan(HpArrays hp, const uint32_t* 
         const unsigned int sum = sat_box(cell_tot, tp.g.nx, tp.g.ny, cx0, cx1, cy0, cy1, cz0, cz1, lane);
         if (first) { if (lane == 0) est[k] = sum; first = false; }
         if (sum <= threshold || len == 1) {
-            if (lane == 0) {
-                if (!slot_used) items[k] = pack_item(k, a, len);
-                else items[tp.n_owned + atomicAdd(n_extra, 1u)] = pack_item(k, a, len);
-            }
-            slot_used = true;
+            if (lane == 0) raw[(size_t)k * 64 + n_out] = ((unsigned long long)sum << 32) | pack_item(k, a, len);
+            n_out++;
         } else {
             if (lane == 0) { s_stack[wv][sp] = ((uint32_t)(a + len / 2) << 8) | (uint32_t)(len / 2); s_stack[wv][sp + 1] = ((uint32_t)a << 8) | (uint32_t)(len / 2); }
             sp += 2;
         }
     }
+    if (lane == 0) n_pieces[k] = (uint8_t)n_out;  // 1..64
+}
+
+// Order the pieces by cost class, heaviest first (a counting sort; the order inside a class is
+// arbitrary).  A tile is replayed by ONE wavefront and the cost per tile spans three orders of magnitude, so
+// the long items must start first for the kernel not to end in a tail of a few waves.
+// q: [0] number of items, [1] the gather's queue head, [2 + c] count, then write cursor, of class c.
+__global__ void __launch_bounds__(256) k_items_hist(const unsigned long long* __restrict__ raw, const uint8_t* __restrict__ n_pieces, int n_tiles,
+                                                    unsigned int* __restrict__ q)
+{
+    __shared__ unsigned int h[ITEM_CLASSES];
+    if (threadIdx.x < ITEM_CLASSES) h[threadIdx.x] = 0;
+    __syncthreads();
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = k < n_tiles ? n_pieces[k] : 0;
+    for (int j = 0; j < n; j++) atomicAdd(&h[item_class((unsigned int)(raw[(size_t)k * 64 + j] >> 32))], 1u);
+    __syncthreads();
+    if (threadIdx.x < ITEM_CLASSES && h[threadIdx.x]) { atomicAdd(&q[2 + threadIdx.x], h[threadIdx.x]); atomicAdd(&q[0], h[threadIdx.x]); }
+}
+__global__ void k_items_bases(unsigned int* __restrict__ q)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    unsigned int run = 0;
+    for (int c = ITEM_CLASSES - 1; c >= 0; c--) { const unsigned int n = q[2 + c]; q[2 + c] = run; run += n; }
+    q[1] = 0;
+}
+__global__ void __launch_bounds__(256) k_items_scatter(const unsigned long long* __restrict__ raw, const uint8_t* __restrict__ n_pieces, int n_tiles,
+                                                       unsigned int* __restrict__ q, uint32_t* __restrict__ items)
+{
+    __shared__ unsigned int h[ITEM_CLASSES], base[ITEM_CLASSES];
+    if (threadIdx.x < ITEM_CLASSES) h[threadIdx.x] = 0;
+    __syncthreads();
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = k < n_tiles ? n_pieces[k] : 0;
+    for (int j = 0; j < n; j++) atomicAdd(&h[item_class((unsigned int)(raw[(size_t)k * 64 + j] >> 32))], 1u);
+    __syncthreads();
+    if (threadIdx.x < ITEM_CLASSES) { base[threadIdx.x] = h[threadIdx.x] ? atomicAdd(&q[2 + threadIdx.x], h[threadIdx.x]) : 0u; h[threadIdx.x] = 0; }
+    __syncthreads();
+    for (int j = 0; j < n; j++) {
+        const unsigned long long w = raw[(size_t)k * 64 + j];
+        const int c = item_class((unsigned int)(w >> 32));
+        items[base[c] + atomicAdd(&h[c], 1u)] = (uint32_t)w;
+    }
 }
 
 template <bool STAMPS>
-__global__ void __launch_bounds__(256) k_gather_tiles(HpArrays hp, DevScene sc, RecArrays rec, const uint32_t* __restrict__ cell_start,
-                                                      TileParams tp, const uint32_t* __restrict__ items, const unsigned int* __restrict__ n_items,
-                                                      unsigned int item_base, unsigned long long* __restrict__ counters)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) k_gather_tiles(HpArrays hp, DevScene sc, RecArrays rec, const uint32_t* __restrict__ cell_start,
+                                                      TileParams tp, const uint32_t* __restrict__ items, unsigned int* __restrict__ q,
+                                                      unsigned long long* __restrict__ counters)
 {
     __shared__ unsigned long long s_key[4][64];
     __shared__ uint32_t s_rec[4][64];
-    __shared__ double s_row[4][64][10];  // the round's candidates in key order: position, geometric normal, flux, key
+    __shared__ double s_row[4][64][10];  // the round's candidates in key order: position, geometric normal, key, flux
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const unsigned int item_i = item_base + blockIdx.x * 4 + wv;
-    if (item_i >= (unsigned int)tp.n_owned + *n_items) return;
+    const int P = hp.P;
+    const double BIG = 1e300;
+    const double thr = tp.gather_r2 * 0.01;
+    const double band_rel = 1e-9 + 8e-15 / thr;
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const int64_t cap = rec.cap;
+    // Persistent wavefronts: each takes the next item of the ordered list until the list is empty
+    // (q[0] = number of items, q[1] = queue head; every wave reaches the break).
+    const unsigned int n_items = q[0];
+    for (;;) {
+    unsigned int item_i = 0;
+    if (lane == 0) item_i = atomicAdd(&q[1], 1u);
+    item_i = (unsigned int)__builtin_amdgcn_readfirstlane((int)item_i);
+    if (item_i >= n_items) break;
     const uint32_t item = items[item_i];
-    if (item == 0xFFFFFFFFu) return;  // a tile without live hitpoints
     const int k = (int)(item >> 12), lane0 = (int)((item >> 6) & 63u), lanes = (int)(item & 63u) + 1;
     const int slot = k * 64 + lane;
-    const int P = hp.P;
     const int p = slot < tp.n_pix ? tp.order[slot] : 0;
     bool live = slot < tp.n_pix && lane >= lane0 && lane < lane0 + lanes;
     if (live) live = hp.valid[p] != 0;
-    if (__ballot(live) == 0) return;
+    if (__ballot(live) == 0) continue;
 
     const unsigned long long t_start = __builtin_amdgcn_s_memtime();
     d3 hpos = mk(0, 0, 0), hn = mk(0, 0, 0), hw = mk(0, 0, 0), hcol = mk(0, 0, 0), acc = mk(0, 0, 0);
@@ -343,11 +398,6 @@ __global__ void __launch_bounds__(256) k_gather_tiles(HpArrays hp, DevScene sc, 
         if (tp.rule == 0) { n = hp.n[p]; acc = mk(hp.flux[p], hp.flux[P + p], hp.flux[2 * P + p]); }
         else { madd = hp.madd[p]; acc = mk(hp.phi[p], hp.phi[P + p], hp.phi[2 * P + p]); }
     }
-    const double BIG = 1e300;
-    const double thr = tp.gather_r2 * 0.01;
-    const double band_rel = 1e-9 + 8e-15 / thr;
-    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    const int64_t cap = rec.cap;
     unsigned int c_cand = 0, c_sel = 0, c_acc = 0, c_round = 0;  // wave-uniform tallies except c_acc (per lane)
     unsigned long long c_pairs = 0;
     unsigned long long st_scan = 0, st_rank = 0, st_apply = 0, st_walk = 0, c_walk = 0;   // diagnostic build only (STAMPS)
@@ -574,7 +624,10 @@ __global__ void __launch_bounds__(256) k_gather_tiles(HpArrays hp, DevScene sc, 
         const unsigned long long cyc = (unsigned long long)(__builtin_amdgcn_s_memtime() - t_start);
         atomicMax(&counters[11], cyc); atomicAdd(&counters[12], cyc);
         atomicMax(&counters[13], ((unsigned long long)c_sel << 24) | (unsigned long long)k);
+        if (STAMPS && tp.item_times) { tp.item_times[2 * (size_t)item_i] = t_start; tp.item_times[2 * (size_t)item_i + 1] = t_start + cyc; }
         if (STAMPS) { atomicAdd(&counters[16], st_scan); atomicAdd(&counters[17], st_rank); atomicAdd(&counters[18], st_apply); atomicAdd(&counters[19], st_walk); atomicAdd(&counters[20], c_walk); }
     }
+    __builtin_amdgcn_wave_barrier();
+    }  // next item
 #undef TSTAMP
 }

@@ -49,6 +49,7 @@ __global__ void k_camera_rays(Camera cam, int W, int H, int sx, int sy, double* 
 __global__ void k_intersect(DevScene sc, const double* __restrict__ rays, int64_t n, int32_t* __restrict__ id,
                             double* __restrict__ out)
 {
+    STAGE_SCENE(sc);
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Hit h;
@@ -176,6 +177,7 @@ __device__ __forceinline__ void eye_pixel(const DevScene& sc, const EyeParams& e
 // One thread per pixel, one XorShift stream per (pass, image index).
 __global__ void __launch_bounds__(256) k_eye_pass(DevScene sc, EyeParams ep, HpArrays hp, unsigned long long* __restrict__ counters)
 {
+    STAGE_SCENE(sc);
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int P = ep.W * ep.H;
     uint32_t rays = 0;
@@ -199,6 +201,7 @@ __global__ void __launch_bounds__(256) k_eye_pass(DevScene sc, EyeParams ep, HpA
 #define DYN_PIXEL 0x80000000u
 __global__ void __launch_bounds__(256) k_eye_classify(DevScene sc, EyeParams ep, HpArrays hp)
 {
+    STAGE_SCENE(sc);
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= ep.W * ep.H) return;
     ProbeRng rng;
@@ -210,6 +213,7 @@ __global__ void __launch_bounds__(256) k_eye_classify(DevScene sc, EyeParams ep,
 
 __global__ void __launch_bounds__(64) k_eye_offsets(DevScene sc, EyeParams ep, HpArrays hp, int32_t* __restrict__ err)
 {
+    STAGE_SCENE(sc);
     const int lane = threadIdx.x;
     const int P = ep.W * ep.H;
     unsigned long long cur = 0;
@@ -248,6 +252,7 @@ __global__ void __launch_bounds__(64) k_eye_offsets(DevScene sc, EyeParams ep, H
 __global__ void __launch_bounds__(256) k_eye_pass_stream(DevScene sc, EyeParams ep, HpArrays hp, unsigned long long* __restrict__ counters,
                                                         int32_t* __restrict__ err)
 {
+    STAGE_SCENE(sc);
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int P = ep.W * ep.H;
     uint32_t rays = 0;
@@ -366,6 +371,7 @@ __global__ void __launch_bounds__(256) k_photon_trace(DevScene sc, TraceParams t
                                                       int32_t* __restrict__ err)
 {
     typedef typename TraceRng<MODE>::type RNG;
+    STAGE_SCENE(sc);
     const int lane = threadIdx.x & 63;
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     uint32_t rays = 0;
@@ -821,8 +827,8 @@ struct sppm_ctx {
     int32_t *d_own_pix, *d_order; int n_own_pix;
     unsigned long long *d_hp_keys, *d_hp_keys_out, *d_hp_bb;
     void* d_sort_tmp; size_t sort_tmp_bytes;
-    uint32_t *d_cell_tot, *d_est, *d_items; unsigned int* d_n_items; unsigned long long* d_est_sum; uint8_t* d_ext_bin; int est_valid;
-    double split_factor, est_per_photon; int64_t est_range; unsigned int extra_items_bound;
+    uint32_t *d_cell_tot, *d_est, *d_items; unsigned long long* d_items_raw; unsigned int* d_item_q; uint8_t* d_n_pieces; unsigned long long* d_est_sum; uint8_t* d_ext_bin; int est_valid;  // d_item_q: [0] items [1] queue head [2..33] per cost class
+    double split_factor, est_per_photon; int64_t est_range;
     int order_valid;
     sppm_sphere* d_spheres; int ns;
     Camera cam;
@@ -918,6 +924,7 @@ static int64_t env_i64(const char* name, int64_t dflt)
 extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres, int32_t n_spheres, void* stream, sppm_ctx** out)
 {
     if (!cfg || !h_spheres || !out || n_spheres < 1) return fail(SPPM_ERR_INVALID, "sppm_create: null argument or empty scene");
+    if (n_spheres > SPPM_MAX_SPHERES) return fail(SPPM_ERR_INVALID, "sppm_create: more than 512 spheres (the brute-force sphere table lives in LDS; larger scenes need a ray acceleration structure, not built yet)");
     if (cfg->width < 1 || cfg->height < 1 || cfg->samples < 1 || cfg->supersamples < 1)
         return fail(SPPM_ERR_INVALID, "sppm_create: width, height, samples, supersamples must be >= 1");
     if ((int64_t)cfg->width * cfg->height > (1ll << 30)) return fail(SPPM_ERR_INVALID, "sppm_create: image too large");
@@ -1031,9 +1038,9 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
             sppm_destroy(c); return fail(SPPM_ERR_HIP, "copying the pixel list failed");
         }
         c->sort_tmp_bytes = 0; c->d_sort_tmp = nullptr; c->order_valid = 0;
-        TRY(dev_alloc(c, &c->d_est, (size_t)c->n_owned + 1)); TRY(dev_alloc(c, &c->d_items, (size_t)c->n_owned * 64 + 64, false));
-        TRY(dev_alloc(c, &c->d_cell_tot, (size_t)c->table_cap / 4 + 1)); TRY(dev_alloc(c, &c->d_n_items, 1)); TRY(dev_alloc(c, &c->d_est_sum, 1)); TRY(dev_alloc(c, &c->d_ext_bin, (size_t)c->n_owned + 1)); c->est_valid = 0;
-        c->split_factor = 4.0; c->est_per_photon = 0.0; c->est_range = 0; c->extra_items_bound = 8192;
+        TRY(dev_alloc(c, &c->d_est, (size_t)c->n_owned + 1)); TRY(dev_alloc(c, &c->d_items, (size_t)c->n_owned * 64 + 64, false)); TRY(dev_alloc(c, &c->d_items_raw, (size_t)c->n_owned * 64 + 64, false));
+        TRY(dev_alloc(c, &c->d_cell_tot, (size_t)c->table_cap / 4 + 1)); TRY(dev_alloc(c, &c->d_item_q, 2 + ITEM_CLASSES)); TRY(dev_alloc(c, &c->d_n_pieces, (size_t)c->n_owned + 1)); TRY(dev_alloc(c, &c->d_est_sum, 1)); TRY(dev_alloc(c, &c->d_ext_bin, (size_t)c->n_owned + 1)); c->est_valid = 0;
+        c->split_factor = 4.0; c->est_per_photon = 0.0; c->est_range = 0;
         { const char* e = getenv("SPPM_SPLIT_FACTOR"); if (e && *e) c->split_factor = atof(e); }
         if (c->n_own_pix > 0) {
             if (rocprim::radix_sort_pairs(nullptr, c->sort_tmp_bytes, c->d_hp_keys, c->d_hp_keys_out, c->d_own_pix, c->d_order,
@@ -1070,6 +1077,7 @@ extern "C" int sppm_destroy(sppm_ctx* c)
 }
 
 static inline DevScene scene_of(const sppm_ctx* c) { DevScene s; s.sp = c->d_spheres; s.ns = c->ns; return s; }
+static inline size_t scene_lds(const sppm_ctx* c) { return (size_t)c->ns * sizeof(sppm_sphere); }  // dynamic LDS of STAGE_SCENE
 static inline int nblk(int64_t n, int b) { return (int)((n + b - 1) / b); }
 
 extern "C" int sppm_camera_rays(sppm_ctx* c, int32_t sx, int32_t sy, double* d_rays)
@@ -1084,7 +1092,7 @@ extern "C" int sppm_intersect(sppm_ctx* c, const double* d_rays, int64_t n, int3
 {
     if (!c || n < 0 || (n > 0 && (!d_rays || !d_id || !d_hit))) return fail(SPPM_ERR_INVALID, "sppm_intersect: bad argument");
     if (n == 0) return SPPM_OK;
-    hipLaunchKernelGGL(k_intersect, dim3(nblk(n, 256)), dim3(256), 0, c->stream, scene_of(c), d_rays, n, d_id, d_hit);
+    hipLaunchKernelGGL(k_intersect, dim3(nblk(n, 256)), dim3(256), scene_lds(c), c->stream, scene_of(c), d_rays, n, d_id, d_hit);
     HIPCHK(hipGetLastError());
     return SPPM_OK;
 }
@@ -1097,7 +1105,7 @@ static int eye_pass_stream(sppm_ctx* c, EyeParams& ep)
     const int64_t paths = (int64_t)c->P * c->cfg.samples * c->cfg.supersamples * c->cfg.supersamples;
     int64_t need = 8 * paths + 4096;
     ep.cnt = c->d_eye_cnt; ep.off = c->d_eye_off; ep.total = c->d_stream_total;
-    hipLaunchKernelGGL(k_eye_classify, dim3(nblk(c->P, 256)), dim3(256), 0, st, scene_of(c), ep, c->hp);
+    hipLaunchKernelGGL(k_eye_classify, dim3(nblk(c->P, 256)), dim3(256), scene_lds(c), st, scene_of(c), ep, c->hp);
     HIPCHK(hipGetLastError());
     unsigned long long total = 0;
     for (int attempt = 0;; attempt++) {
@@ -1107,7 +1115,7 @@ static int eye_pass_stream(sppm_ctx* c, EyeParams& ep)
         HIPCHK(hipMemcpyAsync(c->d_u_eye, c->eye_pending.data(), (size_t)need * 8, hipMemcpyHostToDevice, st));
         HIPCHK(hipMemsetAsync(c->d_err + 4, 0, sizeof(int32_t), st));
         ep.u = c->d_u_eye; ep.u_len = need;
-        hipLaunchKernelGGL(k_eye_offsets, dim3(1), dim3(64), 0, st, scene_of(c), ep, c->hp, c->d_err);
+        hipLaunchKernelGGL(k_eye_offsets, dim3(1), dim3(64), scene_lds(c), st, scene_of(c), ep, c->hp, c->d_err);
         HIPCHK(hipGetLastError());
         int32_t short_stream = 0;
         HIPCHK(hipMemcpyAsync(&short_stream, c->d_err + 4, sizeof short_stream, hipMemcpyDeviceToHost, st));
@@ -1117,7 +1125,7 @@ static int eye_pass_stream(sppm_ctx* c, EyeParams& ep)
         if (attempt >= 6) return fail(SPPM_ERR_OVERFLOW, "sppm_eye_pass: the eye paths consume more of the stream than 512 draws per path");
         need *= 2;
     }
-    hipLaunchKernelGGL(k_eye_pass_stream, dim3(nblk(c->P, 256)), dim3(256), 0, st, scene_of(c), ep, c->hp, c->d_counters, c->d_err);
+    hipLaunchKernelGGL(k_eye_pass_stream, dim3(nblk(c->P, 256)), dim3(256), scene_lds(c), st, scene_of(c), ep, c->hp, c->d_counters, c->d_err);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));  // the upload source shrinks below
     c->eye_pending.erase(c->eye_pending.begin(), c->eye_pending.begin() + (ptrdiff_t)total);
@@ -1150,7 +1158,7 @@ static int prepare_photon_stream(sppm_ctx* c, int32_t pass, int64_t count)
         tp.pass = pass; tp.first = 0; tp.count = len; tp.photons_per_pass = c->cfg.photons_per_pass; tp.seed_photon = c->cfg.seed_photon;
         tp.flux_scale = c->flux_scale; tp.rec_cap = 0; tp.u = c->d_u_ph; tp.u_len = len; tp.start = nullptr; tp.consumed = c->d_ph_consumed;
         const int blocks = (int)std::min<int64_t>(nblk(len, 256), 256 * 4);
-        hipLaunchKernelGGL(k_photon_trace<2>, dim3(blocks), dim3(256), 0, st, scene_of(c), tp, c->rec_buf[c->cur], c->d_rec_count_buf[c->cur],
+        hipLaunchKernelGGL(k_photon_trace<2>, dim3(blocks), dim3(256), scene_lds(c), st, scene_of(c), tp, c->rec_buf[c->cur], c->d_rec_count_buf[c->cur],
                            c->d_trace_next_buf[c->cur], c->d_counters, c->d_err);
         hipLaunchKernelGGL(k_photon_chain, dim3(1), dim3(64), 0, st, c->d_ph_consumed, len, count, c->d_ph_start, c->d_stream_total, c->d_err);
         HIPCHK(hipGetLastError());
@@ -1176,7 +1184,7 @@ extern "C" int sppm_eye_pass(sppm_ctx* c, int32_t pass)
         int rc = eye_pass_stream(c, ep);
         if (rc) return rc;
     } else {
-        hipLaunchKernelGGL(k_eye_pass, dim3(nblk(c->P, 256)), dim3(256), 0, c->stream, scene_of(c), ep, c->hp, c->d_counters);
+        hipLaunchKernelGGL(k_eye_pass, dim3(nblk(c->P, 256)), dim3(256), scene_lds(c), c->stream, scene_of(c), ep, c->hp, c->d_counters);
         HIPCHK(hipGetLastError());
     }
     if (c->gather_mode && c->n_own_pix > 0) {
@@ -1213,9 +1221,9 @@ static int trace_into(sppm_ctx* c, int b, int32_t pass, int64_t first, int64_t c
     if (c->sampler == 1) {
         if (c->stream_pass != pass) return fail(SPPM_ERR_STATE, "reference-stream mode: the pass's stream offsets are made by sppm_photon_pass(pass, 0, photons)");
         tp.u = c->d_u_ph; tp.u_len = c->stream_len; tp.start = c->d_ph_start;
-        hipLaunchKernelGGL(k_photon_trace<1>, dim3(trace_blocks), dim3(256), 0, st, scene_of(c), tp, c->rec_buf[b], c->d_rec_count_buf[b], c->d_trace_next_buf[b], c->d_counters, c->d_err);
+        hipLaunchKernelGGL(k_photon_trace<1>, dim3(trace_blocks), dim3(256), scene_lds(c), st, scene_of(c), tp, c->rec_buf[b], c->d_rec_count_buf[b], c->d_trace_next_buf[b], c->d_counters, c->d_err);
     } else
-        hipLaunchKernelGGL(k_photon_trace<0>, dim3(trace_blocks), dim3(256), 0, st, scene_of(c), tp, c->rec_buf[b], c->d_rec_count_buf[b], c->d_trace_next_buf[b], c->d_counters, c->d_err);
+        hipLaunchKernelGGL(k_photon_trace<0>, dim3(trace_blocks), dim3(256), scene_lds(c), st, scene_of(c), tp, c->rec_buf[b], c->d_rec_count_buf[b], c->d_trace_next_buf[b], c->d_counters, c->d_err);
     if (c->timing) { HIPCHK(hipEventRecord(e1, st)); c->ev_trace.push_back({e0, e1}); }
     HIPCHK(hipGetLastError());
     c->photons_traced += (uint64_t)count;
@@ -1411,42 +1419,46 @@ static int gather_tiles(sppm_ctx* c)
     const double mean_est = c->est_per_photon * (double)range;
     const double thr_d = c->est_per_photon > 0.0 ? std::max(256.0, mean_est * c->split_factor) : 4.0e9;
     const uint32_t split_thr = (uint32_t)std::min(4.0e9, thr_d);
-    HIPCHK(hipMemsetAsync(c->d_n_items, 0, sizeof(unsigned int), st));
+    HIPCHK(hipMemsetAsync(c->d_item_q, 0, sizeof(unsigned int) * (2 + ITEM_CLASSES), st));
     hipLaunchKernelGGL(k_cell_totals, dim3(nblk(g.ncells, 256)), dim3(256), 0, st, c->d_cell_cnt, g.ncells, g.S, c->d_cell_tot);
     hipLaunchKernelGGL(k_sat_axis, dim3(nblk(g.ny * g.nz, 64)), dim3(64), 0, st, c->d_cell_tot, g.nx, g.ny, g.nz, 0);
     hipLaunchKernelGGL(k_sat_axis, dim3(nblk(g.nx * g.nz, 64)), dim3(64), 0, st, c->d_cell_tot, g.nx, g.ny, g.nz, 1);
     hipLaunchKernelGGL(k_sat_axis, dim3(nblk(g.nx * g.ny, 64)), dim3(64), 0, st, c->d_cell_tot, g.nx, g.ny, g.nz, 2);
-    hipLaunchKernelGGL(k_tile_plan, dim3(nblk(c->n_owned, 4)), dim3(256), 0, st, c->hp, c->d_cell_tot, tp, split_thr, c->d_items, c->d_n_items, c->d_est);
+    hipLaunchKernelGGL(k_tile_plan, dim3(nblk(c->n_owned, 4)), dim3(256), 0, st, c->hp, c->d_cell_tot, tp, split_thr, c->d_items_raw, c->d_n_pieces, c->d_est);
+    hipLaunchKernelGGL(k_items_hist, dim3(nblk(c->n_owned, 256)), dim3(256), 0, st, c->d_items_raw, c->d_n_pieces, c->n_owned, c->d_item_q);
+    hipLaunchKernelGGL(k_items_bases, dim3(1), dim3(64), 0, st, c->d_item_q);
+    hipLaunchKernelGGL(k_items_scatter, dim3(nblk(c->n_owned, 256)), dim3(256), 0, st, c->d_items_raw, c->d_n_pieces, c->n_owned, c->d_item_q, c->d_items);
     c->est_valid = 1; c->est_range = range;
-    // the gather grid must cover n_owned own slots + the extra pieces; their count is known only on the
-    // device, so launch for the worst case seen so far (waves beyond the count exit at once)
-    const unsigned int n_items = (unsigned int)c->n_owned + c->extra_items_bound;
+    // persistent wavefronts: 4 per SIMD on every CU (fewer if there are few tiles)
+    const unsigned int n_items = (unsigned int)c->n_owned * 64u + 64u;  // capacity of the item list (diagnostics only)
+    const int gather_blocks = std::max(1, std::min(nblk(c->n_owned, 4), 1024));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     const bool dbg = getenv("SPPM_DEBUG") != nullptr;
     if (dbg) { HIPCHK(hipMemsetAsync(c->d_counters + 8, 0, 16 * sizeof(unsigned long long), st)); }
     if (c->timing || dbg) { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventRecord(e0, st)); }
+    unsigned long long* d_item_times = nullptr;
+    if (getenv("SPPM_ITEM_TIMES") && getenv("SPPM_STAMPS")) {
+        HIPCHK(hipMalloc((void**)&d_item_times, (size_t)n_items * 16));
+        HIPCHK(hipMemsetAsync(d_item_times, 0, (size_t)n_items * 16, st));
+        tp.item_times = d_item_times;
+    }
     if (getenv("SPPM_STAMPS"))
-        hipLaunchKernelGGL(k_gather_tiles<true>, dim3(nblk(n_items, 4)), dim3(256), 0, st, c->hp, scene_of(c), c->rec_s, c->d_cell_start, tp, c->d_items, c->d_n_items, 0u, c->d_counters);
+        hipLaunchKernelGGL(k_gather_tiles<true>, dim3(gather_blocks), dim3(256), 0, st, c->hp, scene_of(c), c->rec_s, c->d_cell_start, tp, c->d_items, c->d_item_q, c->d_counters);
     else
-        hipLaunchKernelGGL(k_gather_tiles<false>, dim3(nblk(n_items, 4)), dim3(256), 0, st, c->hp, scene_of(c), c->rec_s, c->d_cell_start, tp, c->d_items, c->d_n_items, 0u, c->d_counters);
+        hipLaunchKernelGGL(k_gather_tiles<false>, dim3(gather_blocks), dim3(256), 0, st, c->hp, scene_of(c), c->rec_s, c->d_cell_start, tp, c->d_items, c->d_item_q, c->d_counters);
     if (c->timing || dbg) { HIPCHK(hipEventRecord(e1, st)); }
     HIPCHK(hipGetLastError());
     float dbg_ms = 0.f;
     if (dbg) { HIPCHK(hipEventSynchronize(e1)); HIPCHK(hipEventElapsedTime(&dbg_ms, e0, e1)); }
+    if (d_item_times) {
+        std::vector<unsigned long long> t((size_t)n_items * 2);
+        HIPCHK(hipMemcpy(t.data(), d_item_times, t.size() * 8, hipMemcpyDeviceToHost));
+        if (FILE* f = fopen(getenv("SPPM_ITEM_TIMES"), "wb")) { fwrite(t.data(), 8, t.size(), f); fclose(f); }
+        hipFree(d_item_times);
+        tp.item_times = nullptr;
+    }
     if (c->timing) c->ev.push_back({e0, e1});
     else if (dbg) { hipEventDestroy(e0); hipEventDestroy(e1); }
-    {   // pieces beyond the launched worst case (rare): run them now, and remember the new bound
-        unsigned int extra = 0;
-        HIPCHK(hipMemcpyAsync(&extra, c->d_n_items, sizeof extra, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
-        if (extra > c->extra_items_bound) {
-            const unsigned int base = (unsigned int)c->n_owned + c->extra_items_bound;
-            hipLaunchKernelGGL(k_gather_tiles<false>, dim3(nblk(extra - c->extra_items_bound, 4)), dim3(256), 0, st, c->hp, scene_of(c), c->rec_s, c->d_cell_start, tp,
-                               c->d_items, c->d_n_items, base, c->d_counters);
-            HIPCHK(hipGetLastError());
-            c->extra_items_bound = extra + extra / 2;
-        }
-    }
     unsigned long long cnt1[24];
     HIPCHK(hipMemcpyAsync(cnt1, c->d_counters, sizeof cnt1, hipMemcpyDeviceToHost, st));
     rc = finish_batch(c);  // synchronises
