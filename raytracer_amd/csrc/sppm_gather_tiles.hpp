@@ -295,11 +295,25 @@ __global__ void __launch_bounds__(256) k_tile_plan(HpArrays hp, const uint32_t* 
         const int a = (int)(top >> 8), len = (int)(top & 0xffu);
         const bool in = live && lane >= a && lane < a + len;
         if (__ballot(in) == 0) continue;
-        const double rm = wave_max_d(in ? rr : 0.0);
-        const int cx0 = grid_coord(wave_min_d(in ? x : BIG) - rm, tp.g.ox, tp.g.inv_c, tp.g.nx), cx1 = grid_coord(wave_max_d(in ? x : -BIG) + rm, tp.g.ox, tp.g.inv_c, tp.g.nx);
-        const int cy0 = grid_coord(wave_min_d(in ? y : BIG) - rm, tp.g.oy, tp.g.inv_c, tp.g.ny), cy1 = grid_coord(wave_max_d(in ? y : -BIG) + rm, tp.g.oy, tp.g.inv_c, tp.g.ny);
-        const int cz0 = grid_coord(wave_min_d(in ? z : BIG) - rm, tp.g.oz, tp.g.inv_c, tp.g.nz), cz1 = grid_coord(wave_max_d(in ? z : -BIG) + rm, tp.g.oz, tp.g.inv_c, tp.g.nz);
-        const unsigned int sum = sat_box(cell_tot, tp.g.nx, tp.g.ny, cx0, cx1, cy0, cy1, cz0, cz1, lane);
+        // the gather replays the range cluster by cluster (same rule as k_gather_tiles): its cost is the
+        // sum of the records in the clusters' regions, which for a scattered range is far more than the
+        // records in the range's bounding box
+        unsigned int sum = 0;
+        unsigned long long remaining = __ballot(in);
+        while (remaining) {
+            const int seed = __ffsll((long long)remaining) - 1;
+            const double sx = rl_d(x, seed), sy = rl_d(y, seed), sz = rl_d(z, seed);
+            const bool inc = in && ((remaining >> lane) & 1ull) && fabs(x - sx) <= tp.cluster_d && fabs(y - sy) <= tp.cluster_d && fabs(z - sz) <= tp.cluster_d;
+            remaining &= ~__ballot(inc);
+            const double rm = wave_max_d(inc ? rr : 0.0);
+            const int cx0 = grid_coord(wave_min_d(inc ? x : BIG) - rm, tp.g.ox, tp.g.inv_c, tp.g.nx), cx1 = grid_coord(wave_max_d(inc ? x : -BIG) + rm, tp.g.ox, tp.g.inv_c, tp.g.nx);
+            const int cy0 = grid_coord(wave_min_d(inc ? y : BIG) - rm, tp.g.oy, tp.g.inv_c, tp.g.ny), cy1 = grid_coord(wave_max_d(inc ? y : -BIG) + rm, tp.g.oy, tp.g.inv_c, tp.g.ny);
+            const int cz0 = grid_coord(wave_min_d(inc ? z : BIG) - rm, tp.g.oz, tp.g.inv_c, tp.g.nz), cz1 = grid_coord(wave_max_d(inc ? z : -BIG) + rm, tp.g.oz, tp.g.inv_c, tp.g.nz);
+            sum += sat_box(cell_tot, tp.g.nx, tp.g.ny, cx0, cx1, cy0, cy1, cz0, cz1, lane);
+            // every slab of every cluster walks the region's cells whether they hold records or not: a fixed
+            // part worth ~16 records, and 64 cells ~ 16 records of work
+            sum += (unsigned int)((16 + (((long long)(cx1 - cx0 + 1) * (cy1 - cy0 + 1) * (cz1 - cz0 + 1)) >> 2)) * tp.g.S);
+        }
         if (first) { if (lane == 0) est[k] = sum; first = false; }
         if (sum <= threshold || len == 1) {
             if (lane == 0) raw[(size_t)k * 64 + n_out] = ((unsigned long long)sum << 32) | pack_item(k, a, len);
@@ -354,14 +368,23 @@ __global__ void __launch_bounds__(256) k_items_scatter(const unsigned long long*
     }
 }
 
+#ifndef GATHER_WAVES
+#define GATHER_WAVES 4
+#endif
+#if GATHER_WAVES == 4
+#define GATHER_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))
+#else
+#define GATHER_WAVES_ATTR
+#endif
 template <bool STAMPS>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) k_gather_tiles(HpArrays hp, DevScene sc, RecArrays rec, const uint32_t* __restrict__ cell_start,
+__global__ void __launch_bounds__(256) GATHER_WAVES_ATTR k_gather_tiles(HpArrays hp, DevScene sc, RecArrays rec, const uint32_t* __restrict__ cell_start,
                                                       TileParams tp, const uint32_t* __restrict__ items, unsigned int* __restrict__ q,
                                                       unsigned long long* __restrict__ counters)
 {
     __shared__ unsigned long long s_key[4][64];
     __shared__ uint32_t s_rec[4][64];
     __shared__ double s_row[4][64][10];  // the round's candidates in key order: position, geometric normal, key, flux
+    const unsigned long long t_entry = STAMPS ? wall_clock64() : 0ull;  // 100 MHz, one clock for the whole device
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int P = hp.P;
     const double BIG = 1e300;
@@ -369,14 +392,21 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
     const double band_rel = 1e-9 + 8e-15 / thr;
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const int64_t cap = rec.cap;
-    // Persistent wavefronts: each takes the next item of the ordered list until the list is empty
-    // (q[0] = number of items, q[1] = queue head; every wave reaches the break).
+    // Persistent wavefronts: wave w starts with item w (thousands of waves asking one counter at the same
+    // moment would queue up for a millisecond), then each takes the next item of the ordered list until the
+    // list is empty (q[0] = number of items, q[1] = queue head beyond the first gridDim.x*4; every wave
+    // reaches the break).
     const unsigned int n_items = q[0];
-    for (;;) {
-    unsigned int item_i = 0;
-    if (lane == 0) item_i = atomicAdd(&q[1], 1u);
-    item_i = (unsigned int)__builtin_amdgcn_readfirstlane((int)item_i);
+    const unsigned int n_waves = gridDim.x * 4u;
+    for (bool first_item = true;; first_item = false) {
+    unsigned int item_i = blockIdx.x * 4u + (unsigned int)wv;
+    if (!first_item) {
+        if (lane == 0) item_i = n_waves + atomicAdd(&q[1], 1u);
+        item_i = (unsigned int)__builtin_amdgcn_readfirstlane((int)item_i);
+    }
     if (item_i >= n_items) break;
+    // the heaviest few percent run at raised priority: they share their SIMD with three other waves and set the kernel's end
+    if (item_i < (n_items >> 5)) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
     const uint32_t item = items[item_i];
     const int k = (int)(item >> 12), lane0 = (int)((item >> 6) & 63u), lanes = (int)(item & 63u) + 1;
     const int slot = k * 64 + lane;
@@ -386,6 +416,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
     if (__ballot(live) == 0) continue;
 
     const unsigned long long t_start = __builtin_amdgcn_s_memtime();
+    const unsigned long long w_start = STAMPS ? wall_clock64() : 0ull;
     d3 hpos = mk(0, 0, 0), hn = mk(0, 0, 0), hw = mk(0, 0, 0), hcol = mk(0, 0, 0), acc = mk(0, 0, 0);
     double r2 = 0.0;
     int n = 0, madd = 0;
@@ -407,7 +438,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
     // jumps (or where a surface ends).  Lanes far from the seed lane are replayed as a cluster of
     // their own, so that a scattered tile costs the sum of its parts and not their bounding box.
     unsigned long long remaining = __ballot(live);
+    unsigned int n_clusters = 0;
     while (remaining) {
+    n_clusters++;
     const int seed = __ffsll((long long)remaining) - 1;
     const double sx = rl_d(hpos.x, seed), sy = rl_d(hpos.y, seed), sz = rl_d(hpos.z, seed);
     const bool inc = live && ((remaining >> lane) & 1ull) && fabs(hpos.x - sx) <= tp.cluster_d && fabs(hpos.y - sy) <= tp.cluster_d &&
@@ -624,7 +657,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
         const unsigned long long cyc = (unsigned long long)(__builtin_amdgcn_s_memtime() - t_start);
         atomicMax(&counters[11], cyc); atomicAdd(&counters[12], cyc);
         atomicMax(&counters[13], ((unsigned long long)c_sel << 24) | (unsigned long long)k);
-        if (STAMPS && tp.item_times) { tp.item_times[2 * (size_t)item_i] = t_start; tp.item_times[2 * (size_t)item_i + 1] = t_start + cyc; }
+        if (STAMPS && tp.item_times) {  // XCC_ID (hardware register 20, bits 3:0): the clock is per XCD
+            const unsigned long long xcc = (unsigned long long)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15u);
+            tp.item_times[4 * (size_t)item_i] = first_item ? t_entry : w_start; tp.item_times[4 * (size_t)item_i + 1] = (wall_clock64() << 4) | xcc;
+            tp.item_times[4 * (size_t)item_i + 2] = ((unsigned long long)c_sel << 32) | item;
+            tp.item_times[4 * (size_t)item_i + 3] = ((unsigned long long)c_round << 32) | ((unsigned long long)n_clusters << 16) | (unsigned long long)(c_cand >> 6 > 65535u ? 65535u : c_cand >> 6);
+        }
         if (STAMPS) { atomicAdd(&counters[16], st_scan); atomicAdd(&counters[17], st_rank); atomicAdd(&counters[18], st_apply); atomicAdd(&counters[19], st_walk); atomicAdd(&counters[20], c_walk); }
     }
     __builtin_amdgcn_wave_barrier();

@@ -1214,7 +1214,7 @@ static int trace_into(sppm_ctx* c, int b, int32_t pass, int64_t first, int64_t c
     tp.photons_per_pass = c->cfg.photons_per_pass; tp.seed_photon = c->cfg.seed_photon; tp.flux_scale = c->flux_scale; tp.rec_cap = c->rec_buf[b].cap;
     // persistent waves: enough to fill the chip (4 waves per SIMD), never more than the photons need
     HIPCHK(hipMemsetAsync(c->d_trace_next_buf[b], 0, sizeof(unsigned long long), st));
-    const int trace_blocks = (int)std::min<int64_t>(nblk(count, 256), 256 * 4);
+    const int trace_blocks = (int)std::min<int64_t>(nblk(count, 256), env_i64("SPPM_TRACE_BLOCKS", 256 * 4));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->timing) { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventRecord(e0, st)); }
     tp.u = nullptr; tp.u_len = 0; tp.start = nullptr; tp.consumed = nullptr;
@@ -1431,15 +1431,15 @@ static int gather_tiles(sppm_ctx* c)
     c->est_valid = 1; c->est_range = range;
     // persistent wavefronts: 4 per SIMD on every CU (fewer if there are few tiles)
     const unsigned int n_items = (unsigned int)c->n_owned * 64u + 64u;  // capacity of the item list (diagnostics only)
-    const int gather_blocks = std::max(1, std::min(nblk(c->n_owned, 4), 1024));
+    const int gather_blocks = std::max(1, std::min(nblk(c->n_owned, 4), 256 * GATHER_WAVES));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     const bool dbg = getenv("SPPM_DEBUG") != nullptr;
     if (dbg) { HIPCHK(hipMemsetAsync(c->d_counters + 8, 0, 16 * sizeof(unsigned long long), st)); }
     if (c->timing || dbg) { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventRecord(e0, st)); }
     unsigned long long* d_item_times = nullptr;
     if (getenv("SPPM_ITEM_TIMES") && getenv("SPPM_STAMPS")) {
-        HIPCHK(hipMalloc((void**)&d_item_times, (size_t)n_items * 16));
-        HIPCHK(hipMemsetAsync(d_item_times, 0, (size_t)n_items * 16, st));
+        HIPCHK(hipMalloc((void**)&d_item_times, (size_t)n_items * 32));
+        HIPCHK(hipMemsetAsync(d_item_times, 0, (size_t)n_items * 32, st));
         tp.item_times = d_item_times;
     }
     if (getenv("SPPM_STAMPS"))
@@ -1451,7 +1451,7 @@ static int gather_tiles(sppm_ctx* c)
     float dbg_ms = 0.f;
     if (dbg) { HIPCHK(hipEventSynchronize(e1)); HIPCHK(hipEventElapsedTime(&dbg_ms, e0, e1)); }
     if (d_item_times) {
-        std::vector<unsigned long long> t((size_t)n_items * 2);
+        std::vector<unsigned long long> t((size_t)n_items * 4);
         HIPCHK(hipMemcpy(t.data(), d_item_times, t.size() * 8, hipMemcpyDeviceToHost));
         if (FILE* f = fopen(getenv("SPPM_ITEM_TIMES"), "wb")) { fwrite(t.data(), 8, t.size(), f); fclose(f); }
         hipFree(d_item_times);
