@@ -66,4 +66,21 @@ DM_HD double dm_pow5(double c)
     return c4 * c;
 }
 
+/* x / pi, correctly rounded, without the hardware division sequence (the gather divides three flux
+ * components by pi for every accepted photon).  Markstein's scheme: y = RN(1/pi); a first quotient, two
+ * exact-residual corrections with fused multiply-adds.  The last step returns RN(x/pi) whenever the
+ * quotient before it is within one ulp, which the first correction ensures; x = 0 gives 0.  Valid for
+ * finite x whose quotient and residuals stay in the normal range (fluxes do).  tests/test_host.py
+ * compares it with the division on random and on hard (near-midpoint) arguments. */
+DM_HD double dm_div_pi(double x)
+{
+    const double pi = 3.14159265358979323846;
+    const double y = 0.31830988618379067154;  /* RN(1/pi) = 0x1.45f306dc9c883p-2 */
+    double q = x * y;
+    double r = __builtin_fma(-q, pi, x);
+    q = __builtin_fma(r, y, q);
+    r = __builtin_fma(-q, pi, x);
+    return __builtin_fma(r, y, q);
+}
+
 #endif

@@ -607,7 +607,8 @@ __global__ void __launch_bounds__(256) GATHER_WAVES_ATTR k_gather_tiles(HpArrays
                             const double na = n * tp.alpha;
                             double g = (na + tp.alpha) / (na + 1.0);
                             if (n == 0) g = 1;
-                            const d3 add = had(hw, had(hcol, ff)) / SPPM_PI;
+                            const d3 num = had(hw, had(hcol, ff));
+                            const d3 add = mk(dm_div_pi(num.x), dm_div_pi(num.y), dm_div_pi(num.z));  // == num / PI, bit for bit
                             if (take) {
                                 r2 = r2 * g;
                                 n++;

@@ -74,3 +74,29 @@ def test_tile_ownership_partitions_the_image():
             for r in range(0, h, 8):
                 for c in range(0, w, 8):
                     assert len(np.unique(img[r:r + 8, c:c + 8])) == 1
+
+
+def test_divide_by_pi_without_the_divider_is_exact():
+    """raytracer_amd/csrc/detmath.h dm_div_pi (used by the HIP gather in place of `/ PI`, src/sppm2.h:413) returns the
+    correctly rounded quotient: compared with the division on random arguments over 60 decades and on arguments whose
+    quotient lies next to a rounding midpoint."""
+    import ctypes as C
+    import oracle_lib as ol
+    L = ol.lib()
+    L.orc_div_pi.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+    L.orc_div_pi.restype = None
+    rng = np.random.default_rng(7)
+
+    def mismatches(x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        a, b = np.empty_like(x), np.empty_like(x)
+        L.orc_div_pi(x.ctypes.data, x.size, a.ctypes.data, b.ctypes.data)
+        return int((a.view(np.uint64) != b.view(np.uint64)).sum())
+
+    assert mismatches(rng.random(2_000_000) * 10.0 ** rng.integers(-30, 30, 2_000_000)) == 0
+    kk = rng.integers(2 ** 52, 2 ** 53, 1_000_000)
+    ld = np.longdouble
+    xm = ((kk.astype(ld) + ld(0.5)) * ld(np.pi)).astype(np.float64) * 2.0 ** -52   # quotients next to a midpoint
+    for x in (xm, np.nextafter(xm, np.inf), np.nextafter(xm, -np.inf)):
+        assert mismatches(x) == 0
+    assert mismatches(np.array([0.0, 1.0, np.pi, 1e-300, 1e300])) == 0
