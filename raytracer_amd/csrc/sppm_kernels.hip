@@ -512,7 +512,8 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_blocks(const uint32_t* __re
     out[i] = base + x - v;
     if (tid == SCAN_BLOCK - 1) block_sum[blockIdx.x] = base + x;
 }
-__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_tops(uint32_t* __restrict__ block_sum, int nblocks, uint32_t* __restrict__ total_out)
+__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_tops(uint32_t* __restrict__ block_sum, int nblocks, uint32_t* __restrict__ total_out,
+                                                          unsigned long long* __restrict__ records_acc)
 {
     // single block; nblocks <= 16384 handled by a serial carry over chunks of SCAN_BLOCK
     __shared__ uint32_t wave_tot[SCAN_BLOCK / 64];
@@ -539,7 +540,7 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_tops(uint32_t* __restrict__
         if (tid == SCAN_BLOCK - 1) carry = b + x;
         __syncthreads();
     }
-    if (tid == 0) *total_out = carry;
+    if (tid == 0) { *total_out = carry; if (records_acc) atomicAdd(records_acc, (unsigned long long)carry); }
 }
 __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_add(uint32_t* __restrict__ out, const uint32_t* __restrict__ block_sum, uint32_t* __restrict__ cursor,
                                                          size_t n, const uint32_t* __restrict__ total)
@@ -849,7 +850,16 @@ struct sppm_ctx {
     struct { int valid, buf, pass; int64_t first, count; } pre;  // a batch traced ahead of its photon_pass call
     int prefetch;
     int32_t* d_err;                  // 4
-    uint32_t *d_cell_cnt, *d_cell_start, *d_cursor, *d_block_sum, *d_total, *d_rec_bucket;
+    uint32_t *d_cell_cnt, *d_cell_start, *d_cursor, *d_block_sum, *d_total, *d_rec_bucket;  // alias bins[cur]
+    // One set of binning tables and sorted records per record buffer: a batch is binned on the tracer's
+    // stream right after it was traced, while the gather of the batch before it still runs.
+    struct BinSet { RecArrays rec_s; uint32_t *rec_bucket, *cell_cnt, *cell_start, *cursor, *block_sum, *total; TileGrid g; int binned; } bins[2];
+    // Tile statistics travel to the host one batch late (pinned slots, no stream sync in steady state):
+    // they only size the grid and balance the load, never change a result.
+    struct StatSlot { TileStats hs; unsigned long long bbq[6]; unsigned long long cnt[24]; };
+    StatSlot* h_stat; hipEvent_t ev_stat[2]; int stat_w; long stat_n;
+    struct { double lo[3], cell, cluster_d; int64_t dims[3], ncells; int valid; } gs;  // spatial part of the grid, from the last statistics read
+    unsigned long long snap_prev[24]; int snap_prev_valid; long gather_j; int64_t hist_S[4], hist_B[4];
     uint32_t n_buckets;
     int64_t batch_photons;
     // accept tap
@@ -920,6 +930,8 @@ static int64_t env_i64(const char* name, int64_t dflt)
     const char* s = getenv(name);
     return (s && *s) ? atoll(s) : dflt;
 }
+
+static void set_cur(sppm_ctx* c, int b);
 
 extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres, int32_t n_spheres, void* stream, sppm_ctx** out)
 {
@@ -993,13 +1005,13 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
     c->batch_photons = env_i64("SPPM_BATCH_PHOTONS", c->gather_mode ? (1 << 20) : (1 << 18));
     if (c->batch_photons < 1024) c->batch_photons = 1024;
     const int64_t cap = env_i64("SPPM_RECORD_CAP", c->batch_photons * (c->gather_mode ? 4 : 8));
-    c->rec_u.cap = c->rec_s.cap = cap;
+    c->rec_u.cap = cap;
     for (int b = 0; b < 2; b++) {
         c->rec_buf[b].cap = cap;
         TRY(dev_alloc(c, &c->rec_buf[b].key, (size_t)cap, false)); TRY(dev_alloc(c, &c->rec_buf[b].f, 9 * (size_t)cap, false));
         TRY(dev_alloc(c, &c->d_rec_count_buf[b], 1)); TRY(dev_alloc(c, &c->d_trace_next_buf[b], 1));
     }
-    c->cur = 0; c->rec_u = c->rec_buf[0]; c->d_rec_count = c->d_rec_count_buf[0]; c->d_trace_next = c->d_trace_next_buf[0];
+    c->cur = 0; c->rec_u = c->rec_buf[0]; c->d_rec_count = c->d_rec_count_buf[0]; c->d_trace_next = c->d_trace_next_buf[0];  // bins[] aliases: set_cur below, once they exist
     c->pre.valid = 0;
     c->prefetch = (int)env_i64("SPPM_PREFETCH", 1);
     if (c->sampler == 1) {
@@ -1012,14 +1024,24 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
         if (hipEventCreateWithFlags(&c->ev_traced[b], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_free[b], hipEventDisableTiming) != hipSuccess) {
             sppm_destroy(c); return fail(SPPM_ERR_HIP, "creating events failed");
         }
-    TRY(dev_alloc(c, &c->rec_s.key, (size_t)cap, false)); TRY(dev_alloc(c, &c->rec_s.f, 9 * (size_t)cap, false));
-    TRY(dev_alloc(c, &c->d_rec_bucket, (size_t)cap, false));
+
     uint32_t nb = 1024;
     while ((int64_t)nb < cap / 2 && nb < (1u << 24)) nb <<= 1;
     c->n_buckets = nb;
     if (c->gather_mode) nb = (uint32_t)((c->table_cap + SCAN_BLOCK) / SCAN_BLOCK * SCAN_BLOCK);
-    TRY(dev_alloc(c, &c->d_cell_cnt, (size_t)nb)); TRY(dev_alloc(c, &c->d_cell_start, (size_t)nb + 1)); TRY(dev_alloc(c, &c->d_cursor, (size_t)nb));
-    TRY(dev_alloc(c, &c->d_block_sum, (size_t)nb / SCAN_BLOCK + 1)); TRY(dev_alloc(c, &c->d_total, 1));
+    for (int b = 0; b < (c->gather_mode ? 2 : 1); b++) {
+        sppm_ctx::BinSet& B = c->bins[b];
+        B.rec_s.cap = cap; B.binned = 0;
+        TRY(dev_alloc(c, &B.rec_s.key, (size_t)cap, false)); TRY(dev_alloc(c, &B.rec_s.f, 9 * (size_t)cap, false));
+        TRY(dev_alloc(c, &B.rec_bucket, (size_t)cap, false));
+        TRY(dev_alloc(c, &B.cell_cnt, (size_t)nb)); TRY(dev_alloc(c, &B.cell_start, (size_t)nb + 1)); TRY(dev_alloc(c, &B.cursor, (size_t)nb));
+        TRY(dev_alloc(c, &B.block_sum, (size_t)nb / SCAN_BLOCK + 1)); TRY(dev_alloc(c, &B.total, 1));
+    }
+    if (!c->gather_mode) c->bins[1] = c->bins[0];
+    c->h_stat = nullptr; c->ev_stat[0] = c->ev_stat[1] = nullptr; c->stat_w = 0; c->stat_n = 0; c->gs.valid = 0; c->snap_prev_valid = 0; c->gather_j = 0;
+    if (hipHostMalloc((void**)&c->h_stat, 2 * sizeof(sppm_ctx::StatSlot), hipHostMallocDefault) != hipSuccess) { sppm_destroy(c); return fail(SPPM_ERR_HIP, "pinned host memory for the tile statistics"); }
+    for (int b = 0; b < 2; b++)
+        if (hipEventCreateWithFlags(&c->ev_stat[b], hipEventDisableTiming) != hipSuccess) { sppm_destroy(c); return fail(SPPM_ERR_HIP, "creating events failed"); }
     TRY(dev_alloc(c, &c->d_counters, 24)); TRY(dev_alloc(c, &c->d_r2max, 1)); TRY(dev_alloc(c, &c->d_err, 8));
     TRY(dev_alloc(c, &c->d_stats, 1));
     {   // the image indices this rank owns (8x8 screen tiles dealt round-robin), in index order
@@ -1053,6 +1075,7 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
         }
     }
 #undef TRY
+    set_cur(c, 0);
     if (hipStreamSynchronize(c->stream) != hipSuccess) { sppm_destroy(c); return fail(SPPM_ERR_HIP, "sppm_create: stream sync failed"); }
     *out = c;
     return SPPM_OK;
@@ -1068,6 +1091,8 @@ extern "C" int sppm_destroy(sppm_ctx* c)
     for (auto& e : c->ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (auto& e : c->ev_trace) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (void* p : c->allocs) hipFree(p);
+    if (c->h_stat) hipHostFree(c->h_stat);
+    for (int b = 0; b < 2; b++) if (c->ev_stat[b]) hipEventDestroy(c->ev_stat[b]);
     if (c->d_u_eye) hipFree(c->d_u_eye);
     if (c->d_u_ph) hipFree(c->d_u_ph);
     if (c->d_ph_start) hipFree(c->d_ph_start);
@@ -1204,6 +1229,9 @@ extern "C" int sppm_eye_pass(sppm_ctx* c, int32_t pass)
 static void set_cur(sppm_ctx* c, int b)
 {
     c->cur = b; c->rec_u = c->rec_buf[b]; c->d_rec_count = c->d_rec_count_buf[b]; c->d_trace_next = c->d_trace_next_buf[b];
+    const sppm_ctx::BinSet& B = c->bins[b];
+    c->rec_s = B.rec_s; c->d_rec_bucket = B.rec_bucket; c->d_cell_cnt = B.cell_cnt; c->d_cell_start = B.cell_start; c->d_cursor = B.cursor;
+    c->d_block_sum = B.block_sum; c->d_total = B.total;
 }
 
 // launch the tracer for photons [first, first+count) of `pass` into record buffer b on stream st
@@ -1286,12 +1314,11 @@ extern "C" int sppm_append_records(sppm_ctx* c, const double* d_rows, int64_t n,
 
 static inline Own own_of(const sppm_ctx* c) { Own o; o.W = c->cfg.width; o.tiles_x = c->tiles_x; o.tile_first = c->tile_first; o.tile_stride = c->tile_stride; return o; }
 
-static int run_scan(sppm_ctx* c, uint32_t n_padded)
+static int run_scan(sppm_ctx* c, const sppm_ctx::BinSet& B, uint32_t n_padded, hipStream_t st, unsigned long long* records_acc)
 {
-    hipStream_t st = c->stream;
-    hipLaunchKernelGGL(k_scan_blocks, dim3(n_padded / SCAN_BLOCK), dim3(SCAN_BLOCK), 0, st, c->d_cell_cnt, c->d_cell_start, c->d_block_sum);
-    hipLaunchKernelGGL(k_scan_tops, dim3(1), dim3(SCAN_BLOCK), 0, st, c->d_block_sum, (int)(n_padded / SCAN_BLOCK), c->d_total);
-    hipLaunchKernelGGL(k_scan_add, dim3(n_padded / SCAN_BLOCK), dim3(SCAN_BLOCK), 0, st, c->d_cell_start, c->d_block_sum, c->d_cursor, (size_t)n_padded, c->d_total);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(n_padded / SCAN_BLOCK), dim3(SCAN_BLOCK), 0, st, B.cell_cnt, B.cell_start, B.block_sum);
+    hipLaunchKernelGGL(k_scan_tops, dim3(1), dim3(SCAN_BLOCK), 0, st, B.block_sum, (int)(n_padded / SCAN_BLOCK), B.total, records_acc);
+    hipLaunchKernelGGL(k_scan_add, dim3(n_padded / SCAN_BLOCK), dim3(SCAN_BLOCK), 0, st, B.cell_start, B.block_sum, B.cursor, (size_t)n_padded, B.total);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1334,7 +1361,7 @@ static int gather_simple(sppm_ctx* c)
     g.mask = nb - 1;
     HIPCHK(hipMemsetAsync(c->d_cell_cnt, 0, sizeof(uint32_t) * nb, st));
     hipLaunchKernelGGL(k_grid_count, dim3(2048), dim3(256), 0, st, c->rec_u, c->d_rec_count, g, c->d_cell_cnt, c->d_rec_bucket);
-    int rc = run_scan(c, nb);
+    int rc = run_scan(c, c->bins[c->cur], nb, st, nullptr);
     if (rc) return rc;
     hipLaunchKernelGGL(k_grid_scatter, dim3(2048), dim3(256), 0, st, c->rec_u, c->rec_s, c->d_rec_count, c->d_rec_bucket, c->d_cursor);
     GatherParams gp;
@@ -1349,6 +1376,27 @@ static int gather_simple(sppm_ctx* c)
     return finish_batch(c);
 }
 
+// ---- tile gather, host side ---------------------------------------------------------------------------
+// Statistics of the tiles' regions (extent histogram, bounding box, counters): launched on the context's
+// stream into a pinned slot, read by the host one batch later.
+static int stats_launch(sppm_ctx* c)
+{
+    hipStream_t st = c->stream;
+    TileParams tp;
+    memset(&tp, 0, sizeof tp);
+    tp.gather_r2 = c->cfg.gather_radius2; tp.order = c->d_order; tp.n_pix = c->n_own_pix; tp.n_owned = c->n_owned;
+    hipLaunchKernelGGL(k_tile_extent, dim3(nblk(c->n_owned, 4)), dim3(256), 0, st, c->hp, tp, c->d_ext_bin);
+    hipLaunchKernelGGL(k_tile_hist, dim3(1), dim3(1024), 0, st, c->d_ext_bin, c->est_valid ? c->d_est : (const uint32_t*)nullptr, c->n_owned, c->d_stats);
+    HIPCHK(hipGetLastError());
+    sppm_ctx::StatSlot* slot = c->h_stat + c->stat_w;
+    HIPCHK(hipMemcpyAsync(&slot->hs, c->d_stats, sizeof slot->hs, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(slot->bbq, c->d_hp_bb, sizeof slot->bbq, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(slot->cnt, c->d_counters, sizeof slot->cnt, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipEventRecord(c->ev_stat[c->stat_w], st));
+    c->stat_w ^= 1; c->stat_n++;
+    return 0;
+}
+
 static double undo_ord(unsigned long long o)
 {
     const unsigned long long b = (o >> 63) ? (o & 0x7fffffffffffffffull) : ~o;
@@ -1357,70 +1405,128 @@ static double undo_ord(unsigned long long o)
     return d;
 }
 
-// Tile gather: size the (slab, cell) grid from the tiles' current regions, counting-sort the records
-// into it, then one wavefront per 8x8 tile replays its records in key order (k_gather_tiles).
+// Wait for the most recent statistics (already there in steady state) and derive what depends on them:
+// the spatial part of the grid, the cluster distance, the mean record estimate per photon and the slab length.
+static int stats_read(sppm_ctx* c)
+{
+    if (c->stat_n == 0) { int rc = stats_launch(c); if (rc) return rc; }
+    const int r = c->stat_w ^ 1;  // the slot written last
+    HIPCHK(hipEventSynchronize(c->ev_stat[r]));
+    const sppm_ctx::StatSlot& sl = c->h_stat[r];
+    const TileStats& hs = sl.hs;
+    if (hs.live_tiles > 0) {
+        // median of the tiles' region extents, interpolated inside its octave so the cell size moves smoothly
+        int med = 0;
+        double med_frac = 1.0;
+        { unsigned int acc = 0; for (int e = 0; e < 64; e++) { acc += hs.hist[e]; if (2 * acc >= hs.live_tiles) { med = e; med_frac = hs.hist[e] ? 1.0 - (double)(acc - (hs.live_tiles + 1) / 2) / (double)hs.hist[e] : 1.0; break; } } }
+        double cell = std::ldexp(1.0, med - 33) * std::exp2(med_frac) * c->cell_factor;
+        double hi[3];
+        // grid box: the hitpoints' bounding box (made by the eye pass) grown by the largest search radius;
+        // positions outside it (a later pass may move hitpoints) fall into the border cells, on both sides alike
+        const double rgrow = std::sqrt(c->cfg.gather_radius2) * (1.0 + 1e-9) + 1e-9;
+        for (int k = 0; k < 3; k++) { c->gs.lo[k] = undo_ord(sl.bbq[k]) - rgrow; hi[k] = undo_ord(sl.bbq[3 + k]) + rgrow; }
+        for (;;) {
+            c->gs.ncells = 1;
+            for (int k = 0; k < 3; k++) { c->gs.dims[k] = std::max<int64_t>(1, (int64_t)std::ceil((hi[k] - c->gs.lo[k]) / cell)); c->gs.ncells *= c->gs.dims[k]; if (c->gs.ncells > (1ll << 40)) break; }
+            if (c->gs.ncells <= c->table_cap / 4) break;
+            cell *= 1.25;
+        }
+        c->gs.cell = cell;
+        c->gs.cluster_d = std::ldexp(1.0, med - 32);  // upper edge of the median tile extent
+        c->gs.valid = 1;
+        if (c->est_valid && c->est_range > 0) c->est_per_photon = (double)hs.est_sum / (double)hs.live_tiles / (double)c->est_range;
+    } else if (!c->gs.valid) {  // no live hitpoint yet: any grid will do
+        for (int k = 0; k < 3; k++) { c->gs.lo[k] = 0.0; c->gs.dims[k] = 1; }
+        c->gs.ncells = 1; c->gs.cell = 1.0; c->gs.cluster_d = 1.0; c->gs.valid = 1;
+    }
+    // slab length: aim at ~20 in-region candidates per (tile, slab), far from the 64 of one round.  The
+    // snapshot of slot r was taken when gather j-1 began, the one before it when gather j-2 began: their
+    // difference is what gather j-2 did, with the slab length it used.
+    if (c->snap_prev_valid && c->gather_j >= 2 && !getenv("SPPM_SLAB_PHOTONS")) {
+        const double tiles_run = (double)(sl.cnt[7] - c->snap_prev[7]);
+        const int64_t S = c->hist_S[(c->gather_j - 2) & 3], B = c->hist_B[(c->gather_j - 2) & 3];
+        if (tiles_run > 0 && S > 0) {
+            const double avg = (double)(sl.cnt[5] - c->snap_prev[5]) / (tiles_run * (double)S);
+            double f = avg > 0 ? 20.0 / avg : 4.0;
+            f = std::min(4.0, std::max(0.25, f));
+            c->slab_B = std::max<int64_t>(64, (int64_t)((double)B * f));
+        }
+    }
+    memcpy(c->snap_prev, sl.cnt, sizeof c->snap_prev);
+    c->snap_prev_valid = 1;
+    return 0;
+}
+
+// the (slab, cell) grid of a batch of photons [first, first + range): space from the statistics, time from the slab length
+static TileGrid grid_for(const sppm_ctx* c, int64_t first, int64_t range)
+{
+    int64_t B = std::max<int64_t>(64, std::min<int64_t>(c->slab_B, range));
+    int64_t S = (range + B - 1) / B;
+    if (S * c->gs.ncells > c->table_cap) { S = std::max<int64_t>(1, c->table_cap / c->gs.ncells); B = (range + S - 1) / S; S = (range + B - 1) / B; }
+    TileGrid g;
+    g.ox = c->gs.lo[0]; g.oy = c->gs.lo[1]; g.oz = c->gs.lo[2]; g.inv_c = 1.0 / c->gs.cell;
+    g.nx = (int)c->gs.dims[0]; g.ny = (int)c->gs.dims[1]; g.nz = (int)c->gs.dims[2]; g.ncells = (int)c->gs.ncells;
+    g.S = (int)S; g.B = B; g.first = first;
+    return g;
+}
+
+// counting sort of record buffer b into its (slab, cell) table, on stream st
+static int bin_into(sppm_ctx* c, int b, const TileGrid& g, hipStream_t st)
+{
+    sppm_ctx::BinSet& B = c->bins[b];
+    const uint32_t n_table = (uint32_t)((int64_t)g.S * g.ncells);
+    const uint32_t n_padded = (n_table + SCAN_BLOCK - 1) / SCAN_BLOCK * SCAN_BLOCK;
+    HIPCHK(hipMemsetAsync(B.cell_cnt, 0, sizeof(uint32_t) * n_padded, st));
+    hipLaunchKernelGGL(k_bin_count, dim3(2048), dim3(256), 0, st, c->rec_buf[b], c->d_rec_count_buf[b], g, B.cell_cnt, B.rec_bucket, c->d_err);
+    int rc = run_scan(c, B, n_padded, st, c->d_counters + 2);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_grid_scatter, dim3(2048), dim3(256), 0, st, c->rec_buf[b], B.rec_s, c->d_rec_count_buf[b], B.rec_bucket, B.cursor);
+    HIPCHK(hipGetLastError());
+    B.g = g; B.binned = 1;
+    return 0;
+}
+
+// Tile gather of the current record buffer: (bin it if that has not happened on the tracer's stream,)
+// plan the work items from the current radii, replay.  No stream synchronisation: errors are flagged
+// on the device and reported by sppm_check.
 static int gather_tiles(sppm_ctx* c)
 {
     hipStream_t st = c->stream;
-    if (c->n_owned == 0 || c->rec_end == c->rec_first) return finish_batch(c);
+    const int64_t range = c->rec_end - c->rec_first;
+    sppm_ctx::BinSet& BS = c->bins[c->cur];
+    if (c->n_owned == 0 || range == 0) {
+        BS.binned = 0;
+        c->gather_batches++; c->photons_applied += (uint64_t)range; c->rec_first = c->rec_end = 0;
+        HIPCHK(hipMemsetAsync(c->d_rec_count, 0, sizeof(unsigned long long), st));
+        return SPPM_OK;
+    }
+    if (!c->order_valid) return fail(SPPM_ERR_STATE, "sppm_gather: no eye pass has run on this context yet");
+    int rc = stats_read(c);
+    if (rc) return rc;
+    rc = stats_launch(c);  // for the batch after this one
+    if (rc) return rc;
+    if (!BS.binned) { rc = bin_into(c, c->cur, grid_for(c, c->rec_first, range), st); if (rc) return rc; }
+    const TileGrid g = BS.g;
     TileParams tp;
     memset(&tp, 0, sizeof tp);
     tp.gather_r2 = c->cfg.gather_radius2; tp.alpha = c->cfg.alpha; tp.rule = c->cfg.update_rule;
-    if (!c->order_valid) return fail(SPPM_ERR_STATE, "sppm_gather: no eye pass has run on this context yet");
     tp.order = c->d_order; tp.n_pix = c->n_own_pix; tp.n_owned = c->n_owned;
     tp.tap_key = c->d_tap_key; tp.tap_pix = c->d_tap_pix; tp.tap_n = c->d_tap_n; tp.tap_cap = c->tap_cap;
-    // --- statistics of the tiles' regions (and the mean record estimate of the previous batch's plan)
-    TileStats hs;
-    unsigned long long bbq[6];
-    hipLaunchKernelGGL(k_tile_extent, dim3(nblk(c->n_owned, 4)), dim3(256), 0, st, c->hp, tp, c->d_ext_bin);
-    hipLaunchKernelGGL(k_tile_hist, dim3(1), dim3(1024), 0, st, c->d_ext_bin, c->est_valid ? c->d_est : (const uint32_t*)nullptr, c->n_owned, c->d_stats);
-    unsigned long long cnt0[24];
-    HIPCHK(hipMemcpyAsync(&hs, c->d_stats, sizeof hs, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(bbq, c->d_hp_bb, sizeof bbq, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(cnt0, c->d_counters, sizeof cnt0, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    if (hs.live_tiles == 0) return finish_batch(c);
-    // median of the tiles' region extents (upper edge of the log2 bin)
-    int med = 0;
-    double med_frac = 1.0;  // where inside its bin the median falls (bins are octaves, so the cell size moves smoothly from pass to pass)
-    { unsigned int acc = 0; for (int e = 0; e < 64; e++) { acc += hs.hist[e]; if (2 * acc >= hs.live_tiles) { med = e; med_frac = hs.hist[e] ? 1.0 - (double)(acc - (hs.live_tiles + 1) / 2) / (double)hs.hist[e] : 1.0; break; } } }
-    double cell = std::ldexp(1.0, med - 33) * std::exp2(med_frac) * c->cell_factor;
-    double lo[3], hi[3];
-    // grid box: the hitpoints' bounding box (made by the eye pass) grown by the largest search radius
-    const double rgrow = std::sqrt(c->cfg.gather_radius2) * (1.0 + 1e-9) + 1e-9;
-    for (int k = 0; k < 3; k++) { lo[k] = undo_ord(bbq[k]) - rgrow; hi[k] = undo_ord(bbq[3 + k]) + rgrow; }
-    int64_t dims[3], ncells;
-    for (;;) {
-        ncells = 1;
-        for (int k = 0; k < 3; k++) { dims[k] = std::max<int64_t>(1, (int64_t)std::ceil((hi[k] - lo[k]) / cell)); ncells *= dims[k]; if (ncells > (1ll << 40)) break; }
-        if (ncells <= c->table_cap / 4) break;
-        cell *= 1.25;
-    }
-    const int64_t range = c->rec_end - c->rec_first;
-    int64_t B = std::max<int64_t>(64, std::min<int64_t>(c->slab_B, range));
-    int64_t S = (range + B - 1) / B;
-    if (S * ncells > c->table_cap) { S = std::max<int64_t>(1, c->table_cap / ncells); B = (range + S - 1) / S; S = (range + B - 1) / B; }
-    TileGrid g;
-    g.ox = lo[0]; g.oy = lo[1]; g.oz = lo[2]; g.inv_c = 1.0 / cell;
-    g.nx = (int)dims[0]; g.ny = (int)dims[1]; g.nz = (int)dims[2]; g.ncells = (int)ncells;
-    g.S = (int)S; g.B = B; g.first = c->rec_first;
     tp.g = g;
-    tp.cluster_d = std::ldexp(1.0, med - 32);  // upper edge of the median tile extent
-    const uint32_t n_table = (uint32_t)(S * ncells);
-    const uint32_t n_padded = (n_table + SCAN_BLOCK - 1) / SCAN_BLOCK * SCAN_BLOCK;
-    HIPCHK(hipMemsetAsync(c->d_cell_cnt, 0, sizeof(uint32_t) * n_padded, st));
-    hipLaunchKernelGGL(k_bin_count, dim3(2048), dim3(256), 0, st, c->rec_u, c->d_rec_count, g, c->d_cell_cnt, c->d_rec_bucket, c->d_err);
-    int rc = run_scan(c, n_padded);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_grid_scatter, dim3(2048), dim3(256), 0, st, c->rec_u, c->rec_s, c->d_rec_count, c->d_rec_bucket, c->d_cursor);
+    tp.cluster_d = c->gs.cluster_d;
+    const double cell = 1.0 / g.inv_c;
+    const int64_t S = g.S, B = g.B;
+    c->hist_S[c->gather_j & 3] = S; c->hist_B[c->gather_j & 3] = B; c->gather_j++;
+    const bool dbg = getenv("SPPM_DEBUG") != nullptr;
+    unsigned long long cnt0[24];
+    if (dbg) { HIPCHK(hipMemcpyAsync(cnt0, c->d_counters, sizeof cnt0, hipMemcpyDeviceToHost, st)); HIPCHK(hipStreamSynchronize(st)); }
     // --- work items: cut tiles whose region holds far more records than the average tile's.  The
     // threshold comes from the previous batch's mean (scaled by the photon count); the first batch is not cut.
-    if (c->est_valid && c->est_range > 0) c->est_per_photon = (double)hs.est_sum / (double)hs.live_tiles / (double)c->est_range;
     const double mean_est = c->est_per_photon * (double)range;
     const double thr_d = c->est_per_photon > 0.0 ? std::max(256.0, mean_est * c->split_factor) : 4.0e9;
     const uint32_t split_thr = (uint32_t)std::min(4.0e9, thr_d);
     HIPCHK(hipMemsetAsync(c->d_item_q, 0, sizeof(unsigned int) * (2 + ITEM_CLASSES), st));
-    hipLaunchKernelGGL(k_cell_totals, dim3(nblk(g.ncells, 256)), dim3(256), 0, st, c->d_cell_cnt, g.ncells, g.S, c->d_cell_tot);
+    hipLaunchKernelGGL(k_cell_totals, dim3(nblk(g.ncells, 256)), dim3(256), 0, st, BS.cell_cnt, g.ncells, g.S, c->d_cell_tot);
     hipLaunchKernelGGL(k_sat_axis, dim3(nblk(g.ny * g.nz, 64)), dim3(64), 0, st, c->d_cell_tot, g.nx, g.ny, g.nz, 0);
     hipLaunchKernelGGL(k_sat_axis, dim3(nblk(g.nx * g.nz, 64)), dim3(64), 0, st, c->d_cell_tot, g.nx, g.ny, g.nz, 1);
     hipLaunchKernelGGL(k_sat_axis, dim3(nblk(g.nx * g.ny, 64)), dim3(64), 0, st, c->d_cell_tot, g.nx, g.ny, g.nz, 2);
@@ -1433,7 +1539,6 @@ static int gather_tiles(sppm_ctx* c)
     const unsigned int n_items = (unsigned int)c->n_owned * 64u + 64u;  // capacity of the item list (diagnostics only)
     const int gather_blocks = std::max(1, std::min(nblk(c->n_owned, 4), 256 * GATHER_WAVES));
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    const bool dbg = getenv("SPPM_DEBUG") != nullptr;
     if (dbg) { HIPCHK(hipMemsetAsync(c->d_counters + 8, 0, 16 * sizeof(unsigned long long), st)); }
     if (c->timing || dbg) { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventRecord(e0, st)); }
     unsigned long long* d_item_times = nullptr;
@@ -1443,9 +1548,9 @@ static int gather_tiles(sppm_ctx* c)
         tp.item_times = d_item_times;
     }
     if (getenv("SPPM_STAMPS"))
-        hipLaunchKernelGGL(k_gather_tiles<true>, dim3(gather_blocks), dim3(256), 0, st, c->hp, scene_of(c), c->rec_s, c->d_cell_start, tp, c->d_items, c->d_item_q, c->d_counters);
+        hipLaunchKernelGGL(k_gather_tiles<true>, dim3(gather_blocks), dim3(256), 0, st, c->hp, scene_of(c), BS.rec_s, BS.cell_start, tp, c->d_items, c->d_item_q, c->d_counters);
     else
-        hipLaunchKernelGGL(k_gather_tiles<false>, dim3(gather_blocks), dim3(256), 0, st, c->hp, scene_of(c), c->rec_s, c->d_cell_start, tp, c->d_items, c->d_item_q, c->d_counters);
+        hipLaunchKernelGGL(k_gather_tiles<false>, dim3(gather_blocks), dim3(256), 0, st, c->hp, scene_of(c), BS.rec_s, BS.cell_start, tp, c->d_items, c->d_item_q, c->d_counters);
     if (c->timing || dbg) { HIPCHK(hipEventRecord(e1, st)); }
     HIPCHK(hipGetLastError());
     float dbg_ms = 0.f;
@@ -1459,18 +1564,16 @@ static int gather_tiles(sppm_ctx* c)
     }
     if (c->timing) c->ev.push_back({e0, e1});
     else if (dbg) { hipEventDestroy(e0); hipEventDestroy(e1); }
+    BS.binned = 0;
+    c->gather_batches++;
+    c->photons_applied += (uint64_t)range;
+    c->rec_first = c->rec_end = 0;
+    HIPCHK(hipMemsetAsync(c->d_rec_count, 0, sizeof(unsigned long long), st));
+    if (!dbg) return SPPM_OK;
     unsigned long long cnt1[24];
     HIPCHK(hipMemcpyAsync(cnt1, c->d_counters, sizeof cnt1, hipMemcpyDeviceToHost, st));
-    rc = finish_batch(c);  // synchronises
-    if (rc) return rc;
-    // adapt the slab length: aim at ~20 in-region candidates per (tile, slab), far from the 64 of one round
+    HIPCHK(hipStreamSynchronize(st));
     const double tiles_run = (double)(cnt1[7] - cnt0[7]);
-    if (tiles_run > 0 && !getenv("SPPM_SLAB_PHOTONS")) {
-        const double avg = (double)(cnt1[5] - cnt0[5]) / (tiles_run * (double)S);
-        double f = avg > 0 ? 20.0 / avg : 4.0;
-        f = std::min(4.0, std::max(0.25, f));
-        c->slab_B = std::max<int64_t>(64, (int64_t)((double)B * f));
-    }
     if (dbg)
         fprintf(stderr, "[sppm] batch %lld photons: %u items for %d tiles (mean est %.0f), gather %.2f ms, max per tile: sel %llu cand %llu rounds %llu cycles %llu (avg cycles %.0f); cell %.3f grid %dx%dx%d S=%d B=%lld rounds/tile-slab %.2f sel/tile-slab %.2f cand/sel %.2f next B %lld\n",
                 (long long)range, n_items, c->n_owned, mean_est, dbg_ms, cnt1[8], cnt1[9], cnt1[10], cnt1[11], (double)cnt1[12] / std::max(1.0, tiles_run), cell, g.nx, g.ny, g.nz, g.S, (long long)B, (double)(cnt1[6] - cnt0[6]) / std::max(1.0, tiles_run * S),
@@ -1527,6 +1630,7 @@ static int discard_prefetch(sppm_ctx* c)
     HIPCHK(hipStreamSynchronize(c->trace_stream));
     HIPCHK(hipMemsetAsync(c->d_rec_count_buf[b], 0, sizeof(unsigned long long), c->stream));
     HIPCHK(hipEventRecord(c->ev_free[b], c->stream));
+    c->bins[b].binned = 0;
     c->photons_traced -= (uint64_t)c->pre.count;
     c->pre.valid = 0;
     return 0;
@@ -1551,6 +1655,10 @@ extern "C" int sppm_photon_pass(sppm_ctx* c, int32_t pass, int64_t first, int64_
         rc = prepare_photon_stream(c, pass, count);
         if (rc) return rc;
     }
+    if (c->gather_mode && c->n_owned > 0) {  // the grid's spatial part must exist before a batch is binned
+        if (!c->order_valid) return fail(SPPM_ERR_STATE, "sppm_photon_pass: no eye pass has run on this context yet");
+        if (!c->gs.valid) { rc = stats_read(c); if (rc) return rc; }
+    }
     int64_t n = std::min(batch_size(c, c->photons_applied), count);
     int b;
     if (c->pre.valid && c->pre.pass == pass && c->pre.first == first && c->pre.count == n) {
@@ -1563,6 +1671,7 @@ extern "C" int sppm_photon_pass(sppm_ctx* c, int32_t pass, int64_t first, int64_
         HIPCHK(hipStreamWaitEvent(c->trace_stream, c->ev_free[b], 0));
         rc = trace_into(c, b, pass, first, n, c->trace_stream);
         if (rc) return rc;
+        if (c->gather_mode && c->n_owned > 0) { rc = bin_into(c, b, grid_for(c, first, n), c->trace_stream); if (rc) return rc; }
         HIPCHK(hipEventRecord(c->ev_traced[b], c->trace_stream));
     }
     for (int64_t done = 0; done < count;) {
@@ -1575,6 +1684,7 @@ extern "C" int sppm_photon_pass(sppm_ctx* c, int32_t pass, int64_t first, int64_
             HIPCHK(hipStreamWaitEvent(c->trace_stream, c->ev_free[nb], 0));
             rc = trace_into(c, nb, npass, nfirst, nn, c->trace_stream);
             if (rc) return rc;
+            if (c->gather_mode && c->n_owned > 0) { rc = bin_into(c, nb, grid_for(c, nfirst, nn), c->trace_stream); if (rc) return rc; }
             HIPCHK(hipEventRecord(c->ev_traced[nb], c->trace_stream));
         }
         // gather batch b
@@ -1826,7 +1936,7 @@ extern "C" int sppm_counters(sppm_ctx* c, uint64_t h_out[16])
     HIPCHK(hipStreamSynchronize(c->stream));
     int rc = resolve_events(c);
     if (rc) return rc;
-    h_out[0] = d[0] + d[1]; h_out[1] = c->photons_traced; h_out[2] = c->records_total; h_out[3] = d[3]; h_out[4] = d[4];
+    h_out[0] = d[0] + d[1]; h_out[1] = c->photons_traced; h_out[2] = c->records_total + d[2]; h_out[3] = d[3]; h_out[4] = d[4];
     h_out[5] = c->gather_batches; h_out[6] = c->gather_ns; h_out[7] = c->gather_launches;
     h_out[8] = d[5]; h_out[9] = d[6]; h_out[10] = d[7]; h_out[11] = c->trace_ns; h_out[12] = c->trace_launches; h_out[13] = d[1];
     h_out[14] = h_out[15] = 0;
