@@ -78,13 +78,14 @@ struct EyeParams {
 // (:156-315).  t = y*W + x is the pixel's place in the reference's render order.  COMMIT = false runs
 // the same paths without storing anything (used to count draws).
 template <class RNG, bool COMMIT>
-__device__ __forceinline__ void eye_pixel(const DevScene& sc, const EyeParams& ep, const HpArrays& hp, int t, RNG& rng, uint32_t& rays)
+__device__ __forceinline__ void eye_pixel(const DevScene& sc, const EyeParams& ep, const HpArrays& hp, const HpArrays& out, int t, RNG& rng, uint32_t& rays)
 {
     const int P = ep.W * ep.H;
     const int x = t % ep.W, y = t / ep.W;
     const int index = (ep.H - y - 1) * ep.W + x;
     d3 ld = mk(hp.ld[index], hp.ld[P + index], hp.ld[2 * P + index]);
     int valid = hp.valid[index];
+    bool wrote = false;  // a hitpoint was stored for this pixel in this pass
     for (int sy = 0; sy < ep.supersamples; sy++)
         for (int sx = 0; sx < ep.supersamples; sx++)
             for (int s = 0; s < ep.samples; s++) {
@@ -109,15 +110,15 @@ __device__ __forceinline__ void eye_pixel(const DevScene& sc, const EyeParams& e
                         ld = ld + had(weight, est);
                         // create or overwrite the pixel's hitpoint (src/sppm2.h:204-227)
                         if constexpr (COMMIT) {
-                            hp.pos[index] = is.position.x; hp.pos[P + index] = is.position.y; hp.pos[2 * P + index] = is.position.z;
-                            hp.nrm[index] = is.normal.x; hp.nrm[P + index] = is.normal.y; hp.nrm[2 * P + index] = is.normal.z;
-                            hp.w[index] = weight.x; hp.w[P + index] = weight.y; hp.w[2 * P + index] = weight.z;
-                            hp.obj[index] = is.object_id; hp.dist[index] = is.distance;
+                            out.pos[index] = is.position.x; out.pos[P + index] = is.position.y; out.pos[2 * P + index] = is.position.z;
+                            out.nrm[index] = is.normal.x; out.nrm[P + index] = is.normal.y; out.nrm[2 * P + index] = is.normal.z;
+                            out.w[index] = weight.x; out.w[P + index] = weight.y; out.w[2 * P + index] = weight.z;
+                            out.obj[index] = is.object_id; out.dist[index] = is.distance;
+                            wrote = true;
                         }
                         if (!valid) {
                             valid = 1;
                             if constexpr (COMMIT) {
-                                hp.valid[index] = 1;
                                 hp.r2[index] = ep.initial_r2;
                                 hp.n[index] = 0;  // the reference leaves photon_count unset (src/sppm2.h:108-116); its call site passes 0
                                 hp.flux[index] = 0.0; hp.flux[P + index] = 0.0; hp.flux[2 * P + index] = 0.0;
@@ -171,11 +172,23 @@ __device__ __forceinline__ void eye_pixel(const DevScene& sc, const EyeParams& e
                 }
             path_done:;
             }
-    if constexpr (COMMIT) { hp.ld[index] = ld.x; hp.ld[P + index] = ld.y; hp.ld[2 * P + index] = ld.z; }
+    if constexpr (COMMIT) {
+        // `out` is the view the NEXT gather reads (the eye pass of pass i+1 may run while the gather of pass i
+        // still reads `hp`): the direct term, the valid flag, and -- where this pass stored no hitpoint -- the
+        // hitpoint the pixel already had (the reference overwrites a pixel's hitpoint only on a diffuse hit)
+        out.ld[index] = ld.x; out.ld[P + index] = ld.y; out.ld[2 * P + index] = ld.z;
+        out.valid[index] = valid;
+        if (!wrote && valid) {
+            out.pos[index] = hp.pos[index]; out.pos[P + index] = hp.pos[P + index]; out.pos[2 * P + index] = hp.pos[2 * P + index];
+            out.nrm[index] = hp.nrm[index]; out.nrm[P + index] = hp.nrm[P + index]; out.nrm[2 * P + index] = hp.nrm[2 * P + index];
+            out.w[index] = hp.w[index]; out.w[P + index] = hp.w[P + index]; out.w[2 * P + index] = hp.w[2 * P + index];
+            out.obj[index] = hp.obj[index]; out.dist[index] = hp.dist[index];
+        }
+    }
 }
 
 // One thread per pixel, one XorShift stream per (pass, image index).
-__global__ void __launch_bounds__(256) k_eye_pass(DevScene sc, EyeParams ep, HpArrays hp, unsigned long long* __restrict__ counters)
+__global__ void __launch_bounds__(256) k_eye_pass(DevScene sc, EyeParams ep, HpArrays hp, HpArrays out, unsigned long long* __restrict__ counters)
 {
     STAGE_SCENE(sc);
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -184,7 +197,7 @@ __global__ void __launch_bounds__(256) k_eye_pass(DevScene sc, EyeParams ep, HpA
     if (t < P) {
         const int index = (ep.H - t / ep.W - 1) * ep.W + t % ep.W;
         XorShift rng = make_stream(ep.seed_eye, (uint64_t)ep.pass * (uint64_t)P + (uint64_t)index);
-        eye_pixel<XorShift, true>(sc, ep, hp, t, rng, rays);
+        eye_pixel<XorShift, true>(sc, ep, hp, out, t, rng, rays);
     }
     // rays counter: one atomic per wave
     for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off);
@@ -207,7 +220,7 @@ __global__ void __launch_bounds__(256) k_eye_classify(DevScene sc, EyeParams ep,
     ProbeRng rng;
     rng.count = 0; rng.dyn = false;
     uint32_t rays = 0;
-    eye_pixel<ProbeRng, false>(sc, ep, hp, t, rng, rays);
+    eye_pixel<ProbeRng, false>(sc, ep, hp, hp, t, rng, rays);
     ep.cnt[t] = rng.dyn ? DYN_PIXEL : (uint32_t)rng.count;
 }
 
@@ -237,7 +250,7 @@ __global__ void __launch_bounds__(64) k_eye_offsets(DevScene sc, EyeParams ep, H
                     ep.off[t] = cur;
                     StreamRng rng; rng.u = ep.u; rng.pos = (int64_t)cur; rng.end = ep.u_len;
                     uint32_t rays = 0;
-                    eye_pixel<StreamRng, false>(sc, ep, hp, t, rng, rays);
+                    eye_pixel<StreamRng, false>(sc, ep, hp, hp, t, rng, rays);
                     used = (unsigned long long)rng.pos - cur;
                     if (rng.stop()) err[4] = 1;
                 }
@@ -249,7 +262,7 @@ __global__ void __launch_bounds__(64) k_eye_offsets(DevScene sc, EyeParams ep, H
     if (lane == 0) { ep.total[0] = cur; if ((int64_t)cur > ep.u_len) err[4] = 1; }
 }
 
-__global__ void __launch_bounds__(256) k_eye_pass_stream(DevScene sc, EyeParams ep, HpArrays hp, unsigned long long* __restrict__ counters,
+__global__ void __launch_bounds__(256) k_eye_pass_stream(DevScene sc, EyeParams ep, HpArrays hp, HpArrays out, unsigned long long* __restrict__ counters,
                                                         int32_t* __restrict__ err)
 {
     STAGE_SCENE(sc);
@@ -258,7 +271,7 @@ __global__ void __launch_bounds__(256) k_eye_pass_stream(DevScene sc, EyeParams 
     uint32_t rays = 0;
     if (t < P) {
         StreamRng rng; rng.u = ep.u; rng.pos = (int64_t)ep.off[t]; rng.end = ep.u_len;
-        eye_pixel<StreamRng, true>(sc, ep, hp, t, rng, rays);
+        eye_pixel<StreamRng, true>(sc, ep, hp, out, t, rng, rays);
         // the pixel must stop exactly where the walk said the next one starts
         const unsigned long long next = t + 1 < P ? ep.off[t + 1] : ep.total[0];
         if ((unsigned long long)rng.pos != next) err[5] = 1;
@@ -835,7 +848,13 @@ struct sppm_ctx {
     Camera cam;
     double flux_scale;
     std::vector<void*> allocs;
-    HpArrays hp;
+    HpArrays hp;       // the current view (= view[cur_view])
+    // What an eye pass writes (hitpoint geometry, valid flags, direct term, tile order, bounding box) exists
+    // twice: the eye pass of pass i+1 fills the other view on its own stream while the gather of pass i still
+    // reads this one.  Radii, counts and flux are shared (an eye pass only initialises them for new pixels).
+    HpArrays view[2]; int32_t* d_order_v[2]; unsigned long long* d_hp_bb_v[2]; int cur_view;
+    hipStream_t eye_stream; hipEvent_t ev_eye_done, ev_eye_go;
+    struct { int valid, pass; } pre_eye;  // an eye pass computed ahead of its call
     RecArrays rec_u, rec_s;  // unsorted (traced / received), sorted by bucket
     unsigned long long* d_rec_count;
     unsigned long long* d_counters;  // 8: [0] rays [3] candidates [4] updates [5] selected [6] rounds [7] live tile launches
@@ -966,6 +985,7 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
     c->photons_applied = 0;
     c->ns = n_spheres;
     c->trace_stream = nullptr; for (int b = 0; b < 2; b++) { c->ev_traced[b] = nullptr; c->ev_free[b] = nullptr; }
+    c->eye_stream = nullptr; c->ev_eye_done = c->ev_eye_go = nullptr; c->d_order_v[0] = c->d_order_v[1] = nullptr; c->d_hp_bb_v[0] = c->d_hp_bb_v[1] = nullptr;
     c->tap_cap = 0; c->d_tap_key = nullptr; c->d_tap_pix = nullptr; c->d_tap_n = nullptr;
     c->sampler = cfg->sampler; c->eye_eng.seed(cfg->seed_eye);
     c->d_u_eye = c->d_u_ph = nullptr; c->u_eye_cap = c->u_ph_cap = 0; c->d_eye_cnt = nullptr; c->d_ph_start = c->d_ph_consumed = nullptr;
@@ -1001,6 +1021,13 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
     if (cfg->update_rule == 1) {
         TRY(dev_alloc(c, &c->hp.phi, 3 * P)); TRY(dev_alloc(c, &c->hp.tau, 3 * P)); TRY(dev_alloc(c, &c->hp.nd, P)); TRY(dev_alloc(c, &c->hp.madd, P));
     } else { c->hp.phi = c->hp.tau = c->hp.nd = nullptr; c->hp.madd = nullptr; }
+    c->view[0] = c->hp; c->view[1] = c->hp; c->cur_view = 0; c->pre_eye.valid = 0;
+    TRY(dev_alloc(c, &c->view[1].pos, 3 * P)); TRY(dev_alloc(c, &c->view[1].nrm, 3 * P)); TRY(dev_alloc(c, &c->view[1].w, 3 * P));
+    TRY(dev_alloc(c, &c->view[1].ld, 3 * P)); TRY(dev_alloc(c, &c->view[1].dist, P)); TRY(dev_alloc(c, &c->view[1].obj, P)); TRY(dev_alloc(c, &c->view[1].valid, P));
+    if (hipStreamCreateWithFlags(&c->eye_stream, hipStreamNonBlocking) != hipSuccess) { sppm_destroy(c); return fail(SPPM_ERR_HIP, "creating the eye stream failed"); }
+    if (hipEventCreateWithFlags(&c->ev_eye_done, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_eye_go, hipEventDisableTiming) != hipSuccess) {
+        sppm_destroy(c); return fail(SPPM_ERR_HIP, "creating events failed");
+    }
     // record buffers: one batch of photons, ~2.6 records per photon on the Cornell scene; 8x head room
     c->batch_photons = env_i64("SPPM_BATCH_PHOTONS", c->gather_mode ? (1 << 20) : (1 << 18));
     if (c->batch_photons < 1024) c->batch_photons = 1024;
@@ -1053,9 +1080,9 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
         }
         c->n_own_pix = (int)own.size();
         c->n_owned = (c->n_own_pix + 63) / 64;  // virtual tiles of 64 hitpoints
-        TRY(dev_alloc(c, &c->d_own_pix, own.size(), false)); TRY(dev_alloc(c, &c->d_order, own.size(), false));
+        TRY(dev_alloc(c, &c->d_own_pix, own.size(), false)); TRY(dev_alloc(c, &c->d_order_v[0], own.size(), false)); TRY(dev_alloc(c, &c->d_order_v[1], own.size(), false)); c->d_order = c->d_order_v[0];
         TRY(dev_alloc(c, &c->d_hp_keys, own.size(), false)); TRY(dev_alloc(c, &c->d_hp_keys_out, own.size(), false));
-        TRY(dev_alloc(c, &c->d_hp_bb, 6));
+        TRY(dev_alloc(c, &c->d_hp_bb_v[0], 6)); TRY(dev_alloc(c, &c->d_hp_bb_v[1], 6)); c->d_hp_bb = c->d_hp_bb_v[0];
         if (!own.empty() && hipMemcpy(c->d_own_pix, own.data(), own.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
             sppm_destroy(c); return fail(SPPM_ERR_HIP, "copying the pixel list failed");
         }
@@ -1085,6 +1112,9 @@ extern "C" int sppm_destroy(sppm_ctx* c)
 {
     if (!c) return SPPM_OK;
     if (c->trace_stream) hipStreamSynchronize(c->trace_stream);
+    if (c->eye_stream) { hipStreamSynchronize(c->eye_stream); hipStreamDestroy(c->eye_stream); }
+    if (c->ev_eye_done) hipEventDestroy(c->ev_eye_done);
+    if (c->ev_eye_go) hipEventDestroy(c->ev_eye_go);
     hipStreamSynchronize(c->stream);
     for (int b = 0; b < 2; b++) { if (c->ev_traced[b]) hipEventDestroy(c->ev_traced[b]); if (c->ev_free[b]) hipEventDestroy(c->ev_free[b]); }
     if (c->trace_stream) hipStreamDestroy(c->trace_stream);
@@ -1150,7 +1180,7 @@ static int eye_pass_stream(sppm_ctx* c, EyeParams& ep)
         if (attempt >= 6) return fail(SPPM_ERR_OVERFLOW, "sppm_eye_pass: the eye paths consume more of the stream than 512 draws per path");
         need *= 2;
     }
-    hipLaunchKernelGGL(k_eye_pass_stream, dim3(nblk(c->P, 256)), dim3(256), scene_lds(c), st, scene_of(c), ep, c->hp, c->d_counters, c->d_err);
+    hipLaunchKernelGGL(k_eye_pass_stream, dim3(nblk(c->P, 256)), dim3(256), scene_lds(c), st, scene_of(c), ep, c->hp, c->view[1 - c->cur_view], c->d_counters, c->d_err);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));  // the upload source shrinks below
     c->eye_pending.erase(c->eye_pending.begin(), c->eye_pending.begin() + (ptrdiff_t)total);
@@ -1198,31 +1228,72 @@ static int prepare_photon_stream(sppm_ctx* c, int32_t pass, int64_t count)
     return 0;
 }
 
-extern "C" int sppm_eye_pass(sppm_ctx* c, int32_t pass)
+// One eye pass on stream st: reads the current view, writes the other one (hitpoints, valid flags, direct
+// term, bounding box, tile order).  The caller flips the views once the work is ordered before its readers.
+static int eye_launch(sppm_ctx* c, int32_t pass, hipStream_t st)
 {
-    if (!c || pass < 0) return fail(SPPM_ERR_INVALID, "sppm_eye_pass: bad argument");
+    const int nv = 1 - c->cur_view;
     EyeParams ep;
     ep.cam = c->cam; ep.W = c->cfg.width; ep.H = c->cfg.height; ep.samples = c->cfg.samples; ep.supersamples = c->cfg.supersamples;
     ep.pass = pass; ep.seed_eye = c->cfg.seed_eye; ep.initial_r2 = c->cfg.initial_radius2; ep.double_nee = c->cfg.double_nee;
     ep.u = nullptr; ep.u_len = 0; ep.cnt = nullptr; ep.off = nullptr; ep.total = nullptr;
     if (c->sampler == 1) {
-        int rc = eye_pass_stream(c, ep);
+        int rc = eye_pass_stream(c, ep);  // host-driven, on the context's stream
         if (rc) return rc;
     } else {
-        hipLaunchKernelGGL(k_eye_pass, dim3(nblk(c->P, 256)), dim3(256), scene_lds(c), c->stream, scene_of(c), ep, c->hp, c->d_counters);
+        hipLaunchKernelGGL(k_eye_pass, dim3(nblk(c->P, 256)), dim3(256), scene_lds(c), st, scene_of(c), ep, c->hp, c->view[nv], c->d_counters);
         HIPCHK(hipGetLastError());
     }
     if (c->gather_mode && c->n_own_pix > 0) {
         // re-form the gather tiles: sort this rank's hitpoints along a Morton curve of their positions
         unsigned long long init[6] = {~0ull, ~0ull, ~0ull, 0ull, 0ull, 0ull};
-        HIPCHK(hipMemcpyAsync(c->d_hp_bb, init, sizeof init, hipMemcpyHostToDevice, c->stream));
-        hipLaunchKernelGGL(k_hp_bbox, dim3(std::min(nblk(c->n_own_pix, 256), 512)), dim3(256), 0, c->stream, c->hp, c->d_own_pix, c->n_own_pix, c->d_hp_bb);
-        hipLaunchKernelGGL(k_hp_sortkeys, dim3(nblk(c->n_own_pix, 256)), dim3(256), 0, c->stream, c->hp, c->d_own_pix, c->n_own_pix, c->d_hp_bb, c->d_hp_keys);
+        HIPCHK(hipMemcpyAsync(c->d_hp_bb_v[nv], init, sizeof init, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_hp_bbox, dim3(std::min(nblk(c->n_own_pix, 256), 512)), dim3(256), 0, st, c->view[nv], c->d_own_pix, c->n_own_pix, c->d_hp_bb_v[nv]);
+        hipLaunchKernelGGL(k_hp_sortkeys, dim3(nblk(c->n_own_pix, 256)), dim3(256), 0, st, c->view[nv], c->d_own_pix, c->n_own_pix, c->d_hp_bb_v[nv], c->d_hp_keys);
         HIPCHK(hipGetLastError());
-        HIPCHK(rocprim::radix_sort_pairs(c->d_sort_tmp, c->sort_tmp_bytes, c->d_hp_keys, c->d_hp_keys_out, c->d_own_pix, c->d_order,
-                                         (size_t)c->n_own_pix, 0, 3 * MORTON_BITS + 1, c->stream));
-        c->order_valid = 1;
+        HIPCHK(rocprim::radix_sort_pairs(c->d_sort_tmp, c->sort_tmp_bytes, c->d_hp_keys, c->d_hp_keys_out, c->d_own_pix, c->d_order_v[nv],
+                                         (size_t)c->n_own_pix, 0, 3 * MORTON_BITS + 1, st));
     }
+    return 0;
+}
+
+static void flip_view(sppm_ctx* c)
+{
+    c->cur_view ^= 1;
+    c->hp = c->view[c->cur_view]; c->d_order = c->d_order_v[c->cur_view]; c->d_hp_bb = c->d_hp_bb_v[c->cur_view];
+    c->order_valid = 1;
+}
+
+// Eye pass of pass+1 ahead of its call, on the eye stream, while the gather of `pass` runs: eye paths do not
+// depend on photons.  Assumes the caller goes on with sppm_eye_pass(pass + 1); anything else drops it.
+static int eye_prefetch(sppm_ctx* c, int32_t pass)
+{
+    if (!c->prefetch || c->sampler == 1 || c->cfg.update_rule != 0 || c->pre_eye.valid) return 0;
+    // the other view was last read by the pass before this one, whose work is all on the context's stream by now
+    HIPCHK(hipEventRecord(c->ev_eye_go, c->stream));
+    HIPCHK(hipStreamWaitEvent(c->eye_stream, c->ev_eye_go, 0));
+    int rc = eye_launch(c, pass, c->eye_stream);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(c->ev_eye_done, c->eye_stream));
+    c->pre_eye.valid = 1; c->pre_eye.pass = pass;
+    return 0;
+}
+
+extern "C" int sppm_eye_pass(sppm_ctx* c, int32_t pass)
+{
+    if (!c || pass < 0) return fail(SPPM_ERR_INVALID, "sppm_eye_pass: bad argument");
+    if (c->pre_eye.valid) {
+        c->pre_eye.valid = 0;
+        if (c->pre_eye.pass == pass) {  // computed ahead: order it before what follows on the context's stream
+            HIPCHK(hipStreamWaitEvent(c->stream, c->ev_eye_done, 0));
+            flip_view(c);
+            return SPPM_OK;
+        }
+        HIPCHK(hipStreamSynchronize(c->eye_stream));  // not the pass that was expected: its work is dropped
+    }
+    int rc = eye_launch(c, pass, c->stream);
+    if (rc) return rc;
+    flip_view(c);
     return SPPM_OK;
 }
 
@@ -1679,7 +1750,11 @@ extern "C" int sppm_photon_pass(sppm_ctx* c, int32_t pass, int64_t first, int64_
         const int nb = 1 - b;
         int64_t nn = 0; int npass = pass; int64_t nfirst = first + done + n;
         if (done + n < count) nn = std::min(batch_size(c, c->photons_applied + (uint64_t)n), count - done - n);
-        else if (c->prefetch) { npass = pass + 1; nfirst = first; nn = std::min(batch_size(c, c->photons_applied + (uint64_t)n), count); }
+        else if (c->prefetch) {
+            npass = pass + 1; nfirst = first; nn = std::min(batch_size(c, c->photons_applied + (uint64_t)n), count);
+            rc = eye_prefetch(c, pass + 1);
+            if (rc) return rc;
+        }
         if (nn > 0) {
             HIPCHK(hipStreamWaitEvent(c->trace_stream, c->ev_free[nb], 0));
             rc = trace_into(c, nb, npass, nfirst, nn, c->trace_stream);
