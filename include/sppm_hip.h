@@ -80,7 +80,14 @@ typedef struct sppm_config {
                                 photon pass seeded seed_photon + pass (src/sppm2.h:530; the reference takes both
                                 seeds from std::random_device).  Reproduces the reference's image for matched
                                 seeds; single GPU, whole passes only, for validation rather than speed. */
-    int32_t reserved_[2];
+    int32_t ownership;       /* which hitpoints this rank gathers for, when tile_stride > 1:
+                                0: the 8x8 pixel tiles tile_first + k*tile_stride (fixed, known without an eye pass);
+                                1: positions [tile_first*P/tile_stride, (tile_first+1)*P/tile_stride) of the Morton
+                                   order of the FIRST eye pass's hitpoints -- a compact region of space per rank, the
+                                   same partition on every rank without an exchange (the eye pass is replicated).
+                                   Tiles stay as dense as on one GPU and records far from the rank's hitpoints are
+                                   dropped when a batch is binned.  Results are identical either way. */
+    int32_t reserved_[1];
 } sppm_config;
 
 typedef struct sppm_ctx sppm_ctx;
@@ -154,6 +161,9 @@ int sppm_download_hitpoints(sppm_ctx* ctx, int32_t* h_valid, int32_t* h_obj, dou
  * f[n][9] = position, geometric normal, flux.  Returns the count through n (call with NULL arrays
  * to size). */
 int sppm_download_records(sppm_ctx* ctx, uint64_t* h_key, double* h_f, int64_t* n);
+/* d_mask[P] (device, uint8): 1 where this rank owns the pixel's hitpoint (sppm_resolve is meaningful there).
+ * No counterpart in the reference: the image of a multi-GPU run is the sum of the ranks' masked images. */
+int sppm_owned_mask(sppm_ctx* ctx, uint8_t* d_mask);
 /* This rank's image indices in gather-tile order (64 consecutive entries form a tile): the Morton
  * order of the hitpoint positions made by the last eye pass.  Call with NULL to get the count. */
 int sppm_download_tile_order(sppm_ctx* ctx, int32_t* h_order, int64_t* n);

@@ -12,7 +12,7 @@ SYMBOLS = [
     "sppm_last_error", "sppm_device_count", "sppm_create", "sppm_destroy", "sppm_camera_rays", "sppm_intersect",
     "sppm_eye_pass", "sppm_photon_pass", "sppm_trace", "sppm_pack_records", "sppm_append_records", "sppm_gather",
     "sppm_end_pass", "sppm_resolve", "sppm_hdr_pixels", "sppm_save_hdr_file", "sppm_save_ppm_file", "sppm_check",
-    "sppm_download_hitpoints", "sppm_download_records", "sppm_download_tile_order", "sppm_accept_tap", "sppm_download_accepted", "sppm_counters",
+    "sppm_download_hitpoints", "sppm_download_records", "sppm_owned_mask", "sppm_download_tile_order", "sppm_accept_tap", "sppm_download_accepted", "sppm_counters",
     "sppm_set_timing",
 ]
 
@@ -32,7 +32,7 @@ class SppmConfig(C.Structure):
                 ("seed_eye", C.c_uint32), ("seed_photon", C.c_uint32),
                 ("photons_per_pass", C.c_int64),
                 ("tile_first", C.c_int32), ("tile_stride", C.c_int32),
-                ("check_gather_max", C.c_int32), ("sampler", C.c_int32), ("reserved_", C.c_int32 * 2)]
+                ("check_gather_max", C.c_int32), ("sampler", C.c_int32), ("ownership", C.c_int32), ("reserved_", C.c_int32 * 1)]
 
 
 _LIB = None
@@ -69,6 +69,7 @@ def lib():
     L.sppm_download_hitpoints.argtypes = [vp] + [vp] * 7
     L.sppm_download_records.argtypes = [vp, vp, vp, C.POINTER(i64)]
     L.sppm_download_tile_order.argtypes = [vp, vp, C.POINTER(i64)]
+    L.sppm_owned_mask.argtypes = [vp, vp]
     L.sppm_accept_tap.argtypes = [vp, i64]
     L.sppm_download_accepted.argtypes = [vp, vp, vp, C.POINTER(i64)]
     L.sppm_counters.argtypes = [vp, vp]

@@ -578,11 +578,12 @@ __global__ void k_grid_scatter(RecArrays src, RecArrays dst, const unsigned long
 }
 
 // max over valid hitpoints of min(r2, gather_r2), as an ordered-int atomic max on the bit pattern
-struct Own { int W, tiles_x, tile_first, tile_stride; };
-__device__ __forceinline__ bool owned(const Own& o, int p)
+struct Own { const uint8_t* mask; };  // mask[p] != 0: this rank owns pixel p
+__device__ __forceinline__ bool owned(const Own& o, int p) { return o.mask[p] != 0; }
+__global__ void k_mask_from_list(const int32_t* __restrict__ pix, int n, uint8_t* __restrict__ mask)
 {
-    const int t = ((p / o.W) >> 3) * o.tiles_x + ((p % o.W) >> 3) - o.tile_first;
-    return t >= 0 && (t % o.tile_stride) == 0;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) mask[pix[i]] = 1;
 }
 __global__ void k_r2max(HpArrays hp, Own own, double gather_r2, unsigned long long* __restrict__ out)
 {
@@ -839,6 +840,8 @@ struct sppm_ctx {
     TileStats* d_stats;
     // spatial order of this rank's hitpoints (tile gather): own pixel list, Morton keys, sorted order
     int32_t *d_own_pix, *d_order; int n_own_pix;
+    uint8_t* d_own_mask;   // [P]
+    int own_pending;       // spatial ownership: the pixel list is cut out of the first eye pass's Morton order
     unsigned long long *d_hp_keys, *d_hp_keys_out, *d_hp_bb;
     void* d_sort_tmp; size_t sort_tmp_bytes;
     uint32_t *d_cell_tot, *d_est, *d_items; unsigned long long* d_items_raw; unsigned int* d_item_q; uint8_t* d_n_pieces; unsigned long long* d_est_sum; uint8_t* d_ext_bin; int est_valid;  // d_item_q: [0] items [1] queue head [2..33] per cost class
@@ -962,6 +965,7 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
     if (!(cfg->gather_radius2 > 0.0) || !(cfg->initial_radius2 > 0.0) || !(cfg->alpha > 0.0))
         return fail(SPPM_ERR_INVALID, "sppm_create: radii and alpha must be positive");
     if (cfg->update_rule != 0 && cfg->update_rule != 1) return fail(SPPM_ERR_INVALID, "sppm_create: update_rule must be 0 or 1");
+    if (cfg->ownership != 0 && cfg->ownership != 1) return fail(SPPM_ERR_INVALID, "sppm_create: ownership must be 0 (screen tiles) or 1 (ranges of the hitpoints' Morton order)");
     if (cfg->sampler != 0 && cfg->sampler != 1) return fail(SPPM_ERR_INVALID, "sppm_create: sampler must be 0 (XorShift streams) or 1 (reference mt19937 stream)");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
@@ -1074,15 +1078,24 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
     {   // the image indices this rank owns (8x8 screen tiles dealt round-robin), in index order
         std::vector<int32_t> own;
         own.reserve(P / (size_t)c->tile_stride + 64);
+        // ownership 1 (ranges of the Morton order of the first eye pass's hitpoints): every pixel until that
+        // order exists, then the rank's range of it (adopt_range)
+        c->own_pending = cfg->ownership == 1 && c->tile_stride > 1;
         for (int p = 0; p < c->P; p++) {
             const int t = ((p / cfg->width) >> 3) * c->tiles_x + ((p % cfg->width) >> 3) - c->tile_first;
-            if (t >= 0 && t % c->tile_stride == 0) own.push_back(p);
+            if (c->own_pending || (t >= 0 && t % c->tile_stride == 0)) own.push_back(p);
         }
         c->n_own_pix = (int)own.size();
         c->n_owned = (c->n_own_pix + 63) / 64;  // virtual tiles of 64 hitpoints
         TRY(dev_alloc(c, &c->d_own_pix, own.size(), false)); TRY(dev_alloc(c, &c->d_order_v[0], own.size(), false)); TRY(dev_alloc(c, &c->d_order_v[1], own.size(), false)); c->d_order = c->d_order_v[0];
         TRY(dev_alloc(c, &c->d_hp_keys, own.size(), false)); TRY(dev_alloc(c, &c->d_hp_keys_out, own.size(), false));
         TRY(dev_alloc(c, &c->d_hp_bb_v[0], 6)); TRY(dev_alloc(c, &c->d_hp_bb_v[1], 6)); c->d_hp_bb = c->d_hp_bb_v[0];
+        TRY(dev_alloc(c, &c->d_own_mask, P));
+        {
+            std::vector<uint8_t> mask(P, 0);
+            for (int32_t p : own) mask[(size_t)p] = 1;
+            if (hipMemcpy(c->d_own_mask, mask.data(), P, hipMemcpyHostToDevice) != hipSuccess) { sppm_destroy(c); return fail(SPPM_ERR_HIP, "copying the ownership mask failed"); }
+        }
         if (!own.empty() && hipMemcpy(c->d_own_pix, own.data(), own.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
             sppm_destroy(c); return fail(SPPM_ERR_HIP, "copying the pixel list failed");
         }
@@ -1253,6 +1266,26 @@ static int eye_launch(sppm_ctx* c, int32_t pass, hipStream_t st)
         HIPCHK(hipGetLastError());
         HIPCHK(rocprim::radix_sort_pairs(c->d_sort_tmp, c->sort_tmp_bytes, c->d_hp_keys, c->d_hp_keys_out, c->d_own_pix, c->d_order_v[nv],
                                          (size_t)c->n_own_pix, 0, 3 * MORTON_BITS + 1, st));
+        if (c->own_pending) {
+            // Spatial ownership: this rank keeps positions [rank*P/N, (rank+1)*P/N) of the order just made
+            // (every rank computes the same order from the same eye pass, so the ranges partition the
+            // pixels without any exchange).  A compact region of space per rank keeps tiles dense and lets
+            // the binning drop the records far from the rank's hitpoints.
+            const int64_t lo = (int64_t)c->tile_first * c->P / c->tile_stride, hi = (int64_t)(c->tile_first + 1) * c->P / c->tile_stride;
+            const int n = (int)(hi - lo);
+            if (n > 0) {
+                HIPCHK(hipMemcpyAsync(c->d_own_pix, c->d_order_v[nv] + lo, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
+                HIPCHK(hipMemcpyAsync(c->d_order_v[nv], c->d_own_pix, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
+            }
+            HIPCHK(hipMemsetAsync(c->d_own_mask, 0, (size_t)c->P, st));
+            if (n > 0) hipLaunchKernelGGL(k_mask_from_list, dim3(nblk(n, 256)), dim3(256), 0, st, c->d_own_pix, n, c->d_own_mask);
+            c->n_own_pix = n; c->n_owned = (n + 63) / 64; c->own_pending = 0;
+            if (n > 0) {  // the bounding box of what this rank keeps
+                HIPCHK(hipMemcpyAsync(c->d_hp_bb_v[nv], init, sizeof init, hipMemcpyHostToDevice, st));
+                hipLaunchKernelGGL(k_hp_bbox, dim3(std::min(nblk(n, 256), 512)), dim3(256), 0, st, c->view[nv], c->d_own_pix, n, c->d_hp_bb_v[nv]);
+            }
+            HIPCHK(hipGetLastError());
+        }
     }
     return 0;
 }
@@ -1383,7 +1416,7 @@ extern "C" int sppm_append_records(sppm_ctx* c, const double* d_rows, int64_t n,
     return SPPM_OK;
 }
 
-static inline Own own_of(const sppm_ctx* c) { Own o; o.W = c->cfg.width; o.tiles_x = c->tiles_x; o.tile_first = c->tile_first; o.tile_stride = c->tile_stride; return o; }
+static inline Own own_of(const sppm_ctx* c) { Own o; o.mask = c->d_own_mask; return o; }
 
 static int run_scan(sppm_ctx* c, const sppm_ctx::BinSet& B, uint32_t n_padded, hipStream_t st, unsigned long long* records_acc)
 {
@@ -1542,13 +1575,16 @@ static TileGrid grid_for(const sppm_ctx* c, int64_t first, int64_t range)
 }
 
 // counting sort of record buffer b into its (slab, cell) table, on stream st
-static int bin_into(sppm_ctx* c, int b, const TileGrid& g, hipStream_t st)
+static int bin_into(sppm_ctx* c, int b, const TileGrid& g, hipStream_t st, bool drop_far = false)
 {
     sppm_ctx::BinSet& B = c->bins[b];
     const uint32_t n_table = (uint32_t)((int64_t)g.S * g.ncells);
     const uint32_t n_padded = (n_table + SCAN_BLOCK - 1) / SCAN_BLOCK * SCAN_BLOCK;
     HIPCHK(hipMemsetAsync(B.cell_cnt, 0, sizeof(uint32_t) * n_padded, st));
-    hipLaunchKernelGGL(k_bin_count, dim3(2048), dim3(256), 0, st, c->rec_buf[b], c->d_rec_count_buf[b], g, B.cell_cnt, B.rec_bucket, c->d_err);
+    // drop_far: only where the current view's bounding box is final on this stream (not for batches binned ahead)
+    const double reach = std::sqrt(c->cfg.gather_radius2) * (1.0 + 1e-9) + 1e-9;
+    hipLaunchKernelGGL(k_bin_count, dim3(2048), dim3(256), 0, st, c->rec_buf[b], c->d_rec_count_buf[b], g, B.cell_cnt, B.rec_bucket, c->d_err,
+                       drop_far ? c->d_hp_bb : (const unsigned long long*)nullptr, reach);
     int rc = run_scan(c, B, n_padded, st, c->d_counters + 2);
     if (rc) return rc;
     hipLaunchKernelGGL(k_grid_scatter, dim3(2048), dim3(256), 0, st, c->rec_buf[b], B.rec_s, c->d_rec_count_buf[b], B.rec_bucket, B.cursor);
@@ -1576,7 +1612,7 @@ static int gather_tiles(sppm_ctx* c)
     if (rc) return rc;
     rc = stats_launch(c);  // for the batch after this one
     if (rc) return rc;
-    if (!BS.binned) { rc = bin_into(c, c->cur, grid_for(c, c->rec_first, range), st); if (rc) return rc; }
+    if (!BS.binned) { rc = bin_into(c, c->cur, grid_for(c, c->rec_first, range), st, c->tile_stride > 1); if (rc) return rc; }
     const TileGrid g = BS.g;
     TileParams tp;
     memset(&tp, 0, sizeof tp);
@@ -1952,6 +1988,14 @@ extern "C" int sppm_download_records(sppm_ctx* c, uint64_t* h_key, double* h_f, 
         if (h_key) h_key[i] = key[order[i]];
         if (h_f) for (int k = 0; k < 9; k++) h_f[9 * i + k] = f[(size_t)k * cnt + order[i]];
     }
+    return SPPM_OK;
+}
+
+extern "C" int sppm_owned_mask(sppm_ctx* c, uint8_t* d_mask)
+{
+    if (!c || !d_mask) return fail(SPPM_ERR_INVALID, "sppm_owned_mask: null argument");
+    if (c->own_pending) return fail(SPPM_ERR_STATE, "sppm_owned_mask: spatial ownership is decided by the first eye pass");
+    HIPCHK(hipMemcpyAsync(d_mask, c->d_own_mask, (size_t)c->P, hipMemcpyDeviceToDevice, c->stream));
     return SPPM_OK;
 }
 

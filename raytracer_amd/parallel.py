@@ -3,17 +3,18 @@
 What shards and what does not (DESIGN.md "Multi-GPU"):
   * The reference's per-photon update (src/sppm2.h:391-421) is sequential per HITPOINT, not per
     photon: a hitpoint's state depends on the time-ordered photons near it, and on nothing else.
-    So the hitpoints are partitioned across ranks (8x8 pixel tiles dealt round-robin, which also
-    balances bright and dark image regions) and every rank replays, for its own hitpoints, the photon-hit records of the WHOLE pass in key order.
-    The result is bit-identical for every world size.
+    So the hitpoints are partitioned across ranks and every rank replays, for its own hitpoints, the
+    photon-hit records of the WHOLE pass in key order.  The result is bit-identical for every world size.
+    Partition (sppm_config.ownership): 1 = contiguous ranges of the Morton order of the first eye pass's
+    hitpoints, i.e. a compact region of space per rank (default here: tiles stay dense and a rank only
+    bins the records near its region); 0 = 8x8 pixel tiles dealt round-robin.
   * Photon tracing is independent per photon (streams keyed by global photon index).  Two ways to
     give every rank all records of a pass:
+      exchange="allgather" (default): rank r traces photons [r*M, (r+1)*M) and the packed records
+          (1.58 x 80 bytes per photon) are combined with one RCCL all-gather per batch.
       exchange="replicate": every rank traces all photons of the pass itself.  No data-path
-          collective.  On MI355X an FP64 trace of a photon costs far less than moving its ~2.6
-          80-byte records over xGMI, so this is the default.
-      exchange="allgather": rank r traces photons [r*M, (r+1)*M) and the packed records are
-          combined with one RCCL all-gather per batch.
-  * The image is assembled per slice and all-gathered once when it is needed.
+          collective, but the tracing does not scale (measured: it is the bottleneck from 2 ranks on).
+  * The image: every rank resolves its own hitpoints, zeroes the rest, one all-reduce (x + 0 is exact).
 """
 import numpy as np
 
@@ -34,8 +35,8 @@ def owner_of_pixels(width, height, world):
 
 
 class ShardedSppm:
-    def __init__(self, width, height, photons_per_rank, rank=0, world=1, exchange="replicate", spheres=scene.CORNELL_SPHERES,
-                 **cfg_kw):
+    def __init__(self, width, height, photons_per_rank, rank=0, world=1, exchange="allgather", ownership=1,
+                 spheres=scene.CORNELL_SPHERES, **cfg_kw):
         if exchange not in ("replicate", "allgather"):
             raise ValueError("exchange must be 'replicate' or 'allgather'")
         self.W, self.H, self.P = width, height, width * height
@@ -44,7 +45,8 @@ class ShardedSppm:
         self.M = photons_per_rank * world
         self.exchange = exchange if world > 1 else "replicate"
         self.replicated_trace = self.exchange == "replicate"
-        cfg = sppm.make_config(width, height, photons_per_pass=self.M, tile_first=rank, tile_stride=world, **cfg_kw)
+        self.ownership = ownership
+        cfg = sppm.make_config(width, height, photons_per_pass=self.M, tile_first=rank, tile_stride=world, ownership=ownership, **cfg_kw)
         self.ctx = sppm.SppmContext(cfg, spheres)
         self.image = None
         self._rows = self._all = None
@@ -53,7 +55,8 @@ class ShardedSppm:
     def describe(self):
         if self.world == 1:
             return "1 GPU"
-        return f"{self.world} ranks: 8x8 hitpoint tiles dealt round-robin, photon records by {self.exchange}"
+        how = "ranges of the hitpoints' Morton order" if self.ownership == 1 else "8x8 hitpoint tiles dealt round-robin"
+        return f"{self.world} ranks: hitpoints by {how}, photon records by {self.exchange}"
 
     def step(self, i, resolve=True):
         """One SPPM pass: eye pass, photon pass of self.M photons, progressive update, image resolve."""
@@ -95,15 +98,14 @@ class ShardedSppm:
             ctx.gather()
 
     def gather_image(self):
-        """Full image on every rank: every rank's resolve is valid on the tiles it owns; one
-        all-gather, then a select by owner."""
-        import torch
+        """Full image on every rank: a rank's resolve is valid on the hitpoints it owns; the others are zeroed and
+        one all-reduce sums the ranks (exactly one non-zero term per pixel)."""
         import torch.distributed as dist
         if self.world == 1:
             return self.image
-        out = torch.empty((self.world * self.P, 3), dtype=torch.float64, device=self.image.device)
-        dist.all_gather_into_tensor(out, self.image.contiguous())  # concatenated along dim 0 (the form gloo accepts too)
-        return select_by_owner(out.view(self.world, self.P, 3), owner_of_pixels(self.W, self.H, self.world))
+        out = self.image * self.ctx.owned_mask().to(self.image.dtype).unsqueeze(1)
+        dist.all_reduce(out, op=dist.ReduceOp.SUM)
+        return out
 
     def close(self):
         self.ctx.close()

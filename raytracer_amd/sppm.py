@@ -27,7 +27,7 @@ def _sphere_array(table):
 def make_config(width, height, *, samples=1, supersamples=1, camera_position=scene.CAMERA_POSITION, camera_dir=None,
                 camera_up=scene.CAMERA_UP, screen_height=scene.SCREEN_HEIGHT, screen_dist=scene.SCREEN_DIST, alpha=0.7,
                 initial_radius2=25.0, gather_radius2=25.0, gather_max=1 << 40, update_rule=0, double_nee=1,
-                seed_eye=1000, seed_photon=2000, photons_per_pass=0, tile_first=0, tile_stride=0, sampler=0):
+                seed_eye=1000, seed_photon=2000, photons_per_pass=0, tile_first=0, tile_stride=0, sampler=0, ownership=0):
     cfg = capi.SppmConfig()
     cfg.width, cfg.height, cfg.samples, cfg.supersamples = width, height, samples, supersamples
     cfg.camera_position[:] = camera_position
@@ -41,6 +41,7 @@ def make_config(width, height, *, samples=1, supersamples=1, camera_position=sce
     cfg.photons_per_pass = photons_per_pass
     cfg.tile_first, cfg.tile_stride = tile_first, tile_stride
     cfg.sampler = sampler  # 0: XorShift streams; 1: the reference's sequential mt19937 streams
+    cfg.ownership = ownership  # with tile_stride > 1 -- 0: 8x8 screen tiles round-robin; 1: ranges of the hitpoints' Morton order
     return cfg
 
 
@@ -129,6 +130,12 @@ class SppmContext:
 
     def append_records(self, rows, n, photon_first, photon_end):
         capi.check(self.L.sppm_append_records(self.h, rows.data_ptr(), n, photon_first, photon_end))
+
+    def owned_mask(self):
+        """uint8 tensor [P] on this device: 1 where this rank owns the pixel's hitpoint."""
+        m = self.torch.empty((self.P,), dtype=self.torch.uint8, device=self.device)
+        capi.check(self.L.sppm_owned_mask(self.h, m.data_ptr()))
+        return m
 
     # ---- taps ------------------------------------------------------------------------------------
     def hitpoints(self):

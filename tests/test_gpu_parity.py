@@ -223,6 +223,48 @@ def test_record_exchange_equals_local_tracing():
         c.close()
 
 
+def test_spatial_ownership_three_ranks_equal_one_context():
+    """ownership = 1 (every rank keeps a range of the Morton order of the first eye pass's hitpoints), three 'ranks'
+    emulated on one GPU with the all-gather flow: the masks partition the pixels, and merged by mask the hitpoint
+    state and the image equal a single context that did everything itself, bit for bit.  The binning of these
+    ranks drops the records far from their region; nothing near it may be lost."""
+    import torch
+    W, H, M, N = 96, 64, 30000, 3
+    full = sppm.SppmContext(sppm.make_config(W, H, photons_per_pass=M))
+    ranks = [sppm.SppmContext(sppm.make_config(W, H, photons_per_pass=M, tile_first=r, tile_stride=N, ownership=1)) for r in range(N)]
+    rows = [torch.empty((8 * M, 10), dtype=torch.float64, device="cuda") for _ in range(N)]
+    shard = M // N
+    for i in range(3):
+        full.eye_pass(i)
+        full.photon_pass(i, M)
+        cnt = []
+        for r, c in enumerate(ranks):
+            c.eye_pass(i)
+            c.trace(i, r * shard, shard)
+            cnt.append(c.pack_records(rows[r]))
+        for c in ranks:
+            for r in range(N):
+                c.append_records(rows[r], cnt[r], r * shard, (r + 1) * shard)
+            c.gather()
+    for c in [full] + ranks:
+        c.check()
+    masks = [c.owned_mask().cpu().numpy().astype(bool) for c in ranks]
+    assert (np.sum(masks, axis=0) == 1).all(), "the ranks' masks must partition the pixels"
+    sizes = [int(m.sum()) for m in masks]
+    assert max(sizes) - min(sizes) <= 1
+    ref = full.hitpoints()
+    got = [c.hitpoints() for c in ranks]
+    for k in ("n", "r2", "flux"):
+        merged = np.zeros_like(ref[k])
+        for m, g in zip(masks, got):
+            merged[m] = g[k][m]
+        _same(merged, ref[k], k)
+    img = sum(c.resolve(2, M).cpu().numpy() * m[:, None] for c, m in zip(ranks, masks))
+    _same(img, full.resolve(2, M).cpu().numpy(), "image summed over ranks")
+    for c in [full] + ranks:
+        c.close()
+
+
 def test_pack_reports_a_short_row_buffer():
     import torch
     from raytracer_amd import capi
