@@ -131,8 +131,16 @@ int sppm_photon_pass(sppm_ctx* ctx, int32_t pass, int64_t first, int64_t count);
  * geometric normal, flux; any order) and clears the buffer -- what a rank contributes to an all-gather;
  * if cap_rows is too small nothing is cleared, n holds the count needed and SPPM_ERR_OVERFLOW returns.
  * sppm_append_records adds rows (typically another rank's) to the buffer; [photon_first, photon_end) is
- * the photon index range those rows can come from (it sizes the time slabs of the gather). */
+ * the photon index range those rows can come from (it sizes the time slabs of the gather).  On a rank that owns
+ * part of the hitpoints (tile_stride > 1) rows that lie farther than the search radius from the bounding box of its
+ * hitpoints are not stored: none of its hitpoints can accept them. */
 int sppm_trace(sppm_ctx* ctx, int32_t pass, int64_t first, int64_t count);
+/* No counterpart in the reference.  Starts now, on the context's internal streams, work that a later call will
+ * ask for: the trace of photons [first, first+count) of `pass` into the record buffer that is not in use (a
+ * following sppm_trace with the same arguments then only adopts it) and, if `pass` is the pass after the last eye
+ * pass, its eye pass (adopted by sppm_eye_pass(pass)).  Photon paths do not depend on hitpoints and eye paths do
+ * not depend on photons, so results do not change; work that is not asked for afterwards is dropped. */
+int sppm_look_ahead(sppm_ctx* ctx, int32_t pass, int64_t first, int64_t count);
 int sppm_gather(sppm_ctx* ctx);
 int sppm_pack_records(sppm_ctx* ctx, double* d_rows, int64_t cap_rows, int64_t* n);
 int sppm_append_records(sppm_ctx* ctx, const double* d_rows, int64_t n, int64_t photon_first, int64_t photon_end);

@@ -140,21 +140,15 @@ __global__ void k_hp_sortkeys(HpArrays hp, const int32_t* __restrict__ pix, int 
 }
 
 // (slab, cell) bucket of every record of the batch
-// bb != nullptr: the bounding box of this rank's CURRENT hitpoints (ordered-int doubles, made by the eye pass);
-// a record farther than `reach` (>= the search radius) from it in any coordinate cannot be accepted by any of
-// them and is dropped here.  Only used when the box is known to be current (binning on the context's stream).
+// nm.cells != nullptr: records that cannot matter to this rank (near_rank, sppm_kernels.hip) are dropped here.  Only
+// used when the occupancy map is known to be current (binning on the context's stream).
 __global__ void k_bin_count(RecArrays rec, const unsigned long long* __restrict__ rec_count, TileGrid g, uint32_t* __restrict__ cell_cnt,
-                            uint32_t* __restrict__ rec_bucket, int32_t* __restrict__ err, const unsigned long long* __restrict__ bb, double reach)
+                            uint32_t* __restrict__ rec_bucket, int32_t* __restrict__ err, NearMap nm)
 {
     const int64_t n = min((int64_t)*rec_count, rec.cap);
-    double lo[3] = {-1e300, -1e300, -1e300}, hi[3] = {1e300, 1e300, 1e300};
-    if (bb) for (int a = 0; a < 3; a++) { lo[a] = undo_ord_d(bb[a]) - reach; hi[a] = undo_ord_d(bb[3 + a]) + reach; }
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         if (rec.key[i] == ~0ull) { rec_bucket[i] = 0xFFFFFFFFu; continue; }  // a hole left by the tracer's chunked slot reservation
-        if (bb) {
-            const double x = rec.f[i], y = rec.f[rec.cap + i], z = rec.f[2 * rec.cap + i];
-            if (!(x >= lo[0] && x <= hi[0] && y >= lo[1] && y <= hi[1] && z >= lo[2] && z <= hi[2])) { rec_bucket[i] = 0xFFFFFFFFu; continue; }
-        }
+        if (nm.cells && !near_rank(nm, rec.f[i], rec.f[rec.cap + i], rec.f[2 * rec.cap + i])) { rec_bucket[i] = 0xFFFFFFFFu; continue; }
         const int ix = grid_coord(rec.f[i], g.ox, g.inv_c, g.nx);
         const int iy = grid_coord(rec.f[rec.cap + i], g.oy, g.inv_c, g.ny);
         const int iz = grid_coord(rec.f[2 * rec.cap + i], g.oz, g.inv_c, g.nz);

@@ -777,40 +777,136 @@ __global__ void k_hdr_pixels(const double* __restrict__ rgb, int64_t n, uint8_t*
 }
 
 // ---- record exchange between ranks: SoA buffer <-> packed rows of 10 doubles (key bits, 9 fields) -------
-__global__ void k_pack_records(RecArrays rec, const unsigned long long* __restrict__ rec_count, double* __restrict__ rows, int64_t cap_rows,
+// One wavefront per WAVE_ROWS buffer slots, in groups of 64: a first sweep counts the valid ones, ONE atomic per
+// wave reserves a contiguous run of rows (thousands of waves asking one counter per 64 slots would queue up on
+// it), a second sweep writes the rows, staged through LDS so that the row-major side is accessed with
+// consecutive lanes on consecutive doubles.
+#define WAVE_ROWS 1024
+__global__ void __launch_bounds__(256) k_pack_records(RecArrays rec, const unsigned long long* __restrict__ rec_count, double* __restrict__ rows, int64_t cap_rows,
                                unsigned long long* __restrict__ n_out)
 {
+    __shared__ double s_row[4][64 * 10];
     const int64_t n = min((int64_t)*rec_count, rec.cap);
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const unsigned long long key = rec.key[i];
-        if (key == REC_INVALID) continue;
-        const unsigned long long at = atomicAdd(n_out, 1ull);
-        if ((int64_t)at >= cap_rows) continue;  // counted, not stored: the host reports the overflow
-        double* r = rows + 10 * at;
-        r[0] = __longlong_as_double((long long)key);
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t w0 = ((int64_t)blockIdx.x * 4 + wv) * WAVE_ROWS;
+    if (w0 >= n) return;
+    int total = 0;
+    for (int g = 0; g < WAVE_ROWS / 64; g++) {
+        const int64_t i = w0 + g * 64 + lane;
+        total += __popcll(__ballot(i < n && rec.key[i] != REC_INVALID));
+    }
+    if (total == 0) return;
+    unsigned long long at = 0;
+    if (lane == 0) at = atomicAdd(n_out, (unsigned long long)total);
+    at = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(at >> 32)) << 32) |
+         (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)at);
+    for (int g = 0; g < WAVE_ROWS / 64; g++) {
+        const int64_t i = w0 + g * 64 + lane;
+        const unsigned long long key = i < n ? rec.key[i] : REC_INVALID;
+        const bool has = key != REC_INVALID;
+        const unsigned long long m = __ballot(has);
+        if (m == 0) continue;
+        const int cnt = __popcll(m);
+        if (has) {
+            double* r = s_row[wv] + 10 * __popcll(m & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
+            r[0] = __longlong_as_double((long long)key);
 #pragma unroll
-        for (int c = 0; c < 9; c++) r[1 + c] = rec.f[c * rec.cap + i];
+            for (int c = 0; c < 9; c++) r[1 + c] = rec.f[c * rec.cap + i];
+        }
+        __builtin_amdgcn_wave_barrier();
+        // rows at .. at+cnt-1, as far as they fit (the count is complete either way: the host reports the overflow)
+        const int64_t fit = min((int64_t)cnt, max((int64_t)0, cap_rows - (int64_t)at));
+        for (int64_t j = lane; j < fit * 10; j += 64) rows[(int64_t)at * 10 + j] = s_row[wv][j];
+        __builtin_amdgcn_wave_barrier();
+        at += (unsigned long long)cnt;
     }
 }
-__global__ void k_append_records(RecArrays rec, unsigned long long* __restrict__ rec_count, const double* __restrict__ rows, int64_t n,
-                                 int32_t* __restrict__ err)
+// ---- which records can matter to this rank ---------------------------------------------------------------
+// A coarse occupancy map over the bounding box of the rank's hitpoints (grown by the search radius), NEAR_DIM
+// cells per axis.  k_mark_near sets every cell that the box [pos - r, pos + r] of a valid hitpoint of the rank
+// overlaps, r = sqrt(min(r2, search r2)) at that moment.  Radii only shrink, so whenever the map is used later a
+// hitpoint can only accept records inside the box that was marked for it: a record whose cell is not set is
+// dropped when rows are appended or a batch is binned.  Coordinates clamp into the map (monotone, so "the cells a
+// box overlaps" survives the clamp).
+#define NEAR_DIM 64
+struct NearMap { const unsigned long long* bb; const uint8_t* cells; double reach; };  // bb: ordered-int doubles, min[3] max[3]
+__device__ __forceinline__ double near_undo(unsigned long long o)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool has = i < n;
-    const unsigned long long m = __ballot(has);
-    if (m == 0) return;
-    const int lane = threadIdx.x & 63;
+    return __longlong_as_double((long long)((o >> 63) ? (o & 0x7fffffffffffffffull) : ~o));
+}
+__device__ __forceinline__ int near_coord(const unsigned long long* bb, double reach, int a, double v)
+{
+    const double lo = near_undo(bb[a]) - reach, ext = near_undo(bb[3 + a]) + reach - lo;
+    const double f = floor((v - lo) / (ext / (double)NEAR_DIM));
+    return f < 0.0 ? 0 : (f > (double)(NEAR_DIM - 1) ? NEAR_DIM - 1 : (int)f);
+}
+__device__ __forceinline__ bool near_rank(const NearMap& nm, double x, double y, double z)
+{
+    if (!(near_undo(nm.bb[0]) <= near_undo(nm.bb[3]))) return false;  // the rank has no valid hitpoint
+    const int ix = near_coord(nm.bb, nm.reach, 0, x), iy = near_coord(nm.bb, nm.reach, 1, y), iz = near_coord(nm.bb, nm.reach, 2, z);
+    return nm.cells[(iz * NEAR_DIM + iy) * NEAR_DIM + ix] != 0;
+}
+__global__ void k_mark_near(HpArrays hp, const int32_t* __restrict__ pix, int n, const unsigned long long* __restrict__ bb, double reach,
+                            double gather_r2, uint8_t* __restrict__ cells)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int p = pix[i], P = hp.P;
+    if (!hp.valid[p]) return;
+    const double r = sqrt(fmin(hp.r2[p], gather_r2)) * (1.0 + 1e-9) + 1e-9;
+    const double x = hp.pos[p], y = hp.pos[P + p], z = hp.pos[2 * P + p];
+    const int x0 = near_coord(bb, reach, 0, x - r), x1 = near_coord(bb, reach, 0, x + r);
+    const int y0 = near_coord(bb, reach, 1, y - r), y1 = near_coord(bb, reach, 1, y + r);
+    const int z0 = near_coord(bb, reach, 2, z - r), z1 = near_coord(bb, reach, 2, z + r);
+    for (int iz = z0; iz <= z1; iz++)
+        for (int iy = y0; iy <= y1; iy++)
+            for (int ix = x0; ix <= x1; ix++) cells[(iz * NEAR_DIM + iy) * NEAR_DIM + ix] = 1;
+}
+
+// nm.cells != nullptr: rows that cannot matter to this rank (near_rank) are not stored.
+__global__ void __launch_bounds__(256) k_append_records(RecArrays rec, unsigned long long* __restrict__ rec_count, const double* __restrict__ rows, int64_t n,
+                                                        int32_t* __restrict__ err, NearMap nm)
+{
+    __shared__ double s_row[4][64 * 10];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t w0 = ((int64_t)blockIdx.x * 4 + wv) * WAVE_ROWS;
+    if (w0 >= n) return;
+    // first sweep: which rows of this wave's WAVE_ROWS matter to the rank (one bit mask per group of 64)
+    unsigned long long keep[WAVE_ROWS / 64];
+    int total = 0;
+#pragma unroll
+    for (int g = 0; g < WAVE_ROWS / 64; g++) {
+        const int64_t i = w0 + g * 64 + lane;
+        bool has = i < n;
+        if (has && nm.cells) has = near_rank(nm, rows[10 * i + 1], rows[10 * i + 2], rows[10 * i + 3]);
+        keep[g] = __ballot(has);
+        total += __popcll(keep[g]);
+    }
+    if (total == 0) return;
     unsigned long long base = 0;
-    if (lane == __ffsll((long long)m) - 1) base = atomicAdd(rec_count, (unsigned long long)__popcll(m));
+    if (lane == 0) base = atomicAdd(rec_count, (unsigned long long)total);  // one reservation per wave
     base = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) |
            (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)base);
-    if (!has) return;
-    const int64_t slot = (int64_t)base + __popcll(m & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
-    if (slot >= rec.cap) { err[0] = 1; return; }
-    const double* r = rows + 10 * i;
-    rec.key[slot] = (unsigned long long)__double_as_longlong(r[0]);
+    if ((int64_t)base + total > rec.cap) { if (lane == 0) err[0] = 1; return; }
+    // second sweep: the kept rows, staged through LDS (consecutive lanes read consecutive doubles)
 #pragma unroll
-    for (int c = 0; c < 9; c++) rec.f[c * rec.cap + slot] = r[1 + c];
+    for (int g = 0; g < WAVE_ROWS / 64; g++) {
+        const unsigned long long m = keep[g];
+        if (m == 0) continue;
+        const int64_t g0 = w0 + g * 64;
+        const int64_t here = min((int64_t)64, n - g0);
+        for (int64_t j = lane; j < here * 10; j += 64) s_row[wv][j] = rows[g0 * 10 + j];
+        __builtin_amdgcn_wave_barrier();
+        if ((m >> lane) & 1ull) {
+            const double* r = s_row[wv] + 10 * lane;
+            const int64_t slot = (int64_t)base + __popcll(m & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
+            rec.key[slot] = (unsigned long long)__double_as_longlong(r[0]);
+#pragma unroll
+            for (int c = 0; c < 9; c++) rec.f[c * rec.cap + slot] = r[1 + c];
+        }
+        __builtin_amdgcn_wave_barrier();
+        base += (unsigned long long)__popcll(m);
+    }
 }
 
 #include "sppm_gather_tiles.hpp"
@@ -855,9 +951,10 @@ struct sppm_ctx {
     // What an eye pass writes (hitpoint geometry, valid flags, direct term, tile order, bounding box) exists
     // twice: the eye pass of pass i+1 fills the other view on its own stream while the gather of pass i still
     // reads this one.  Radii, counts and flux are shared (an eye pass only initialises them for new pixels).
-    HpArrays view[2]; int32_t* d_order_v[2]; unsigned long long* d_hp_bb_v[2]; int cur_view;
+    HpArrays view[2]; int32_t* d_order_v[2]; unsigned long long* d_hp_bb_v[2]; uint8_t* d_near_v[2]; uint8_t* d_near; int cur_view;
     hipStream_t eye_stream; hipEvent_t ev_eye_done, ev_eye_go;
     struct { int valid, pass; } pre_eye;  // an eye pass computed ahead of its call
+    int last_eye_pass;
     RecArrays rec_u, rec_s;  // unsorted (traced / received), sorted by bucket
     unsigned long long* d_rec_count;
     unsigned long long* d_counters;  // 8: [0] rays [3] candidates [4] updates [5] selected [6] rounds [7] live tile launches
@@ -979,9 +1076,11 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
     c->tile_first = cfg->tile_stride > 0 ? cfg->tile_first : 0;
     if (c->tile_first < 0 || c->tile_first >= c->tile_stride) { delete c; return fail(SPPM_ERR_INVALID, "sppm_create: need 0 <= tile_first < tile_stride"); }
     c->gather_mode = (int)env_i64("SPPM_GATHER_TILES", 1);
-    c->table_cap = env_i64("SPPM_TABLE_CAP", 1ll << 24);
+    // (slab, cell) entries: a rank of an N-GPU run sees N times the photons per batch over its part of the
+    // space, so it needs N times the slabs for the same number of candidates per tile and slab
+    c->table_cap = env_i64("SPPM_TABLE_CAP", (1ll << 24) * std::min(8, std::max(1, cfg->tile_stride)));
     if (c->table_cap < 4096) c->table_cap = 4096;
-    if (c->table_cap > (1ll << 24)) c->table_cap = 1ll << 24;
+    if (c->table_cap > (1ll << 28)) c->table_cap = 1ll << 28;
     c->cell_factor = 0.35;
     { const char* e = getenv("SPPM_CELL_FACTOR"); if (e && *e) c->cell_factor = atof(e); }
     c->slab_B = env_i64("SPPM_SLAB_PHOTONS", 1024);
@@ -1025,7 +1124,7 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
     if (cfg->update_rule == 1) {
         TRY(dev_alloc(c, &c->hp.phi, 3 * P)); TRY(dev_alloc(c, &c->hp.tau, 3 * P)); TRY(dev_alloc(c, &c->hp.nd, P)); TRY(dev_alloc(c, &c->hp.madd, P));
     } else { c->hp.phi = c->hp.tau = c->hp.nd = nullptr; c->hp.madd = nullptr; }
-    c->view[0] = c->hp; c->view[1] = c->hp; c->cur_view = 0; c->pre_eye.valid = 0;
+    c->view[0] = c->hp; c->view[1] = c->hp; c->cur_view = 0; c->pre_eye.valid = 0; c->last_eye_pass = -1;
     TRY(dev_alloc(c, &c->view[1].pos, 3 * P)); TRY(dev_alloc(c, &c->view[1].nrm, 3 * P)); TRY(dev_alloc(c, &c->view[1].w, 3 * P));
     TRY(dev_alloc(c, &c->view[1].ld, 3 * P)); TRY(dev_alloc(c, &c->view[1].dist, P)); TRY(dev_alloc(c, &c->view[1].obj, P)); TRY(dev_alloc(c, &c->view[1].valid, P));
     if (hipStreamCreateWithFlags(&c->eye_stream, hipStreamNonBlocking) != hipSuccess) { sppm_destroy(c); return fail(SPPM_ERR_HIP, "creating the eye stream failed"); }
@@ -1035,7 +1134,8 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
     // record buffers: one batch of photons, ~2.6 records per photon on the Cornell scene; 8x head room
     c->batch_photons = env_i64("SPPM_BATCH_PHOTONS", c->gather_mode ? (1 << 20) : (1 << 18));
     if (c->batch_photons < 1024) c->batch_photons = 1024;
-    const int64_t cap = env_i64("SPPM_RECORD_CAP", c->batch_photons * (c->gather_mode ? 4 : 8));
+    // a rank of a multi-GPU run keeps the records near its hitpoints out of tile_stride x as many photons
+    const int64_t cap = env_i64("SPPM_RECORD_CAP", c->batch_photons * ((c->gather_mode && c->tile_stride == 1) ? 4 : 8));
     c->rec_u.cap = cap;
     for (int b = 0; b < 2; b++) {
         c->rec_buf[b].cap = cap;
@@ -1090,6 +1190,7 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
         TRY(dev_alloc(c, &c->d_own_pix, own.size(), false)); TRY(dev_alloc(c, &c->d_order_v[0], own.size(), false)); TRY(dev_alloc(c, &c->d_order_v[1], own.size(), false)); c->d_order = c->d_order_v[0];
         TRY(dev_alloc(c, &c->d_hp_keys, own.size(), false)); TRY(dev_alloc(c, &c->d_hp_keys_out, own.size(), false));
         TRY(dev_alloc(c, &c->d_hp_bb_v[0], 6)); TRY(dev_alloc(c, &c->d_hp_bb_v[1], 6)); c->d_hp_bb = c->d_hp_bb_v[0];
+        TRY(dev_alloc(c, &c->d_near_v[0], (size_t)NEAR_DIM * NEAR_DIM * NEAR_DIM)); TRY(dev_alloc(c, &c->d_near_v[1], (size_t)NEAR_DIM * NEAR_DIM * NEAR_DIM)); c->d_near = c->d_near_v[0];
         TRY(dev_alloc(c, &c->d_own_mask, P));
         {
             std::vector<uint8_t> mask(P, 0);
@@ -1147,6 +1248,13 @@ extern "C" int sppm_destroy(sppm_ctx* c)
 static inline DevScene scene_of(const sppm_ctx* c) { DevScene s; s.sp = c->d_spheres; s.ns = c->ns; return s; }
 static inline size_t scene_lds(const sppm_ctx* c) { return (size_t)c->ns * sizeof(sppm_sphere); }  // dynamic LDS of STAGE_SCENE
 static inline int nblk(int64_t n, int b) { return (int)((n + b - 1) / b); }
+static inline double reach_of(const sppm_ctx* c) { return std::sqrt(c->cfg.gather_radius2) * (1.0 + 1e-9) + 1e-9; }
+// the occupancy map of the CURRENT view (valid on the context's stream once the eye pass is ordered before it)
+static inline NearMap near_map(const sppm_ctx* c, bool use)
+{
+    NearMap nm; nm.bb = c->d_hp_bb; nm.cells = use ? c->d_near : nullptr; nm.reach = reach_of(c);
+    return nm;
+}
 
 extern "C" int sppm_camera_rays(sppm_ctx* c, int32_t sx, int32_t sy, double* d_rays)
 {
@@ -1286,6 +1394,11 @@ static int eye_launch(sppm_ctx* c, int32_t pass, hipStream_t st)
             }
             HIPCHK(hipGetLastError());
         }
+        if (c->tile_stride > 1) {  // which coarse cells lie near this rank's hitpoints (drops far records, k_mark_near)
+            HIPCHK(hipMemsetAsync(c->d_near_v[nv], 0, (size_t)NEAR_DIM * NEAR_DIM * NEAR_DIM, st));
+            hipLaunchKernelGGL(k_mark_near, dim3(nblk(c->n_own_pix, 256)), dim3(256), 0, st, c->view[nv], c->d_own_pix, c->n_own_pix, c->d_hp_bb_v[nv], reach_of(c), c->cfg.gather_radius2, c->d_near_v[nv]);
+            HIPCHK(hipGetLastError());
+        }
     }
     return 0;
 }
@@ -1293,7 +1406,7 @@ static int eye_launch(sppm_ctx* c, int32_t pass, hipStream_t st)
 static void flip_view(sppm_ctx* c)
 {
     c->cur_view ^= 1;
-    c->hp = c->view[c->cur_view]; c->d_order = c->d_order_v[c->cur_view]; c->d_hp_bb = c->d_hp_bb_v[c->cur_view];
+    c->hp = c->view[c->cur_view]; c->d_order = c->d_order_v[c->cur_view]; c->d_hp_bb = c->d_hp_bb_v[c->cur_view]; c->d_near = c->d_near_v[c->cur_view];
     c->order_valid = 1;
 }
 
@@ -1320,6 +1433,7 @@ extern "C" int sppm_eye_pass(sppm_ctx* c, int32_t pass)
         if (c->pre_eye.pass == pass) {  // computed ahead: order it before what follows on the context's stream
             HIPCHK(hipStreamWaitEvent(c->stream, c->ev_eye_done, 0));
             flip_view(c);
+            c->last_eye_pass = pass;
             return SPPM_OK;
         }
         HIPCHK(hipStreamSynchronize(c->eye_stream));  // not the pass that was expected: its work is dropped
@@ -1327,6 +1441,7 @@ extern "C" int sppm_eye_pass(sppm_ctx* c, int32_t pass)
     int rc = eye_launch(c, pass, c->stream);
     if (rc) return rc;
     flip_view(c);
+    c->last_eye_pass = pass;
     return SPPM_OK;
 }
 
@@ -1368,11 +1483,44 @@ extern "C" int sppm_trace(sppm_ctx* c, int32_t pass, int64_t first, int64_t coun
     if (c->cfg.photons_per_pass > 0 && first + count > c->cfg.photons_per_pass)
         return fail(SPPM_ERR_INVALID, "sppm_trace: photon range exceeds photons_per_pass");
     if (count == 0) return SPPM_OK;
+    if (c->pre.valid && c->pre.pass == pass && c->pre.first == first && c->pre.count == count && c->rec_end == c->rec_first) {
+        // traced ahead (sppm_look_ahead): order it before what follows and make its buffer the current one
+        HIPCHK(hipStreamWaitEvent(c->stream, c->ev_traced[c->pre.buf], 0));
+        set_cur(c, c->pre.buf);
+        c->bins[c->pre.buf].binned = 0;
+        c->pre.valid = 0;
+        c->rec_first = first; c->rec_end = first + count;
+        return SPPM_OK;
+    }
     if (c->pre.valid && c->pre.buf == c->cur) set_cur(c, 1 - c->cur);  // keep away from a batch traced ahead
     int rc = trace_into(c, c->cur, pass, first, count, c->stream);
     if (rc) return rc;
     if (c->rec_end == c->rec_first) { c->rec_first = first; c->rec_end = first + count; }
     else { c->rec_first = std::min(c->rec_first, first); c->rec_end = std::max(c->rec_end, first + count); }
+    return SPPM_OK;
+}
+
+static int discard_prefetch(sppm_ctx* c);
+static int eye_prefetch(sppm_ctx* c, int32_t pass);
+
+extern "C" int sppm_look_ahead(sppm_ctx* c, int32_t pass, int64_t first, int64_t count)
+{
+    if (!c || pass < 0 || first < 0 || count < 0) return fail(SPPM_ERR_INVALID, "sppm_look_ahead: bad argument");
+    if (c->cfg.photons_per_pass > 0 && first + count > c->cfg.photons_per_pass)
+        return fail(SPPM_ERR_INVALID, "sppm_look_ahead: photon range exceeds photons_per_pass");
+    if (c->sampler == 1 || count == 0) return SPPM_OK;  // the sequential reference stream cannot run ahead
+    int rc = discard_prefetch(c);
+    if (rc) return rc;
+    const int nb = 1 - c->cur;
+    // the other buffer is free once everything enqueued on the context's stream so far has run
+    HIPCHK(hipEventRecord(c->ev_free[nb], c->stream));
+    HIPCHK(hipStreamWaitEvent(c->trace_stream, c->ev_free[nb], 0));
+    HIPCHK(hipMemsetAsync(c->d_rec_count_buf[nb], 0, sizeof(unsigned long long), c->trace_stream));
+    rc = trace_into(c, nb, pass, first, count, c->trace_stream);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(c->ev_traced[nb], c->trace_stream));
+    c->pre.valid = 1; c->pre.buf = nb; c->pre.pass = pass; c->pre.first = first; c->pre.count = count;
+    if (pass == c->last_eye_pass + 1) { rc = eye_prefetch(c, pass); if (rc) return rc; }
     return SPPM_OK;
 }
 
@@ -1391,7 +1539,7 @@ extern "C" int sppm_pack_records(sppm_ctx* c, double* d_rows, int64_t cap_rows, 
 {
     if (!c || !n || cap_rows < 0 || (cap_rows > 0 && !d_rows)) return fail(SPPM_ERR_INVALID, "sppm_pack_records: bad argument");
     HIPCHK(hipMemsetAsync(c->d_r2max, 0, sizeof(unsigned long long), c->stream));  // reused as the row counter
-    hipLaunchKernelGGL(k_pack_records, dim3(1024), dim3(256), 0, c->stream, c->rec_u, c->d_rec_count, d_rows, cap_rows, c->d_r2max);
+    hipLaunchKernelGGL(k_pack_records, dim3(nblk(c->rec_u.cap, 4 * WAVE_ROWS)), dim3(256), 0, c->stream, c->rec_u, c->d_rec_count, d_rows, cap_rows, c->d_r2max);
     HIPCHK(hipGetLastError());
     unsigned long long cnt = 0;
     HIPCHK(hipMemcpyAsync(&cnt, c->d_r2max, sizeof cnt, hipMemcpyDeviceToHost, c->stream));
@@ -1411,7 +1559,8 @@ extern "C" int sppm_append_records(sppm_ctx* c, const double* d_rows, int64_t n,
         else { c->rec_first = std::min(c->rec_first, photon_first); c->rec_end = std::max(c->rec_end, photon_end); }
     }
     if (n == 0) return SPPM_OK;
-    hipLaunchKernelGGL(k_append_records, dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->rec_u, c->d_rec_count, d_rows, n, c->d_err);
+    const bool drop_far = c->gather_mode && c->tile_stride > 1 && c->order_valid && c->n_own_pix > 0;
+    hipLaunchKernelGGL(k_append_records, dim3(nblk(n, 4 * WAVE_ROWS)), dim3(256), 0, c->stream, c->rec_u, c->d_rec_count, d_rows, n, c->d_err, near_map(c, drop_far));
     HIPCHK(hipGetLastError());
     return SPPM_OK;
 }
@@ -1581,10 +1730,9 @@ static int bin_into(sppm_ctx* c, int b, const TileGrid& g, hipStream_t st, bool 
     const uint32_t n_table = (uint32_t)((int64_t)g.S * g.ncells);
     const uint32_t n_padded = (n_table + SCAN_BLOCK - 1) / SCAN_BLOCK * SCAN_BLOCK;
     HIPCHK(hipMemsetAsync(B.cell_cnt, 0, sizeof(uint32_t) * n_padded, st));
-    // drop_far: only where the current view's bounding box is final on this stream (not for batches binned ahead)
-    const double reach = std::sqrt(c->cfg.gather_radius2) * (1.0 + 1e-9) + 1e-9;
+    // drop_far: only where the current view's occupancy map is final on this stream (not for batches binned ahead)
     hipLaunchKernelGGL(k_bin_count, dim3(2048), dim3(256), 0, st, c->rec_buf[b], c->d_rec_count_buf[b], g, B.cell_cnt, B.rec_bucket, c->d_err,
-                       drop_far ? c->d_hp_bb : (const unsigned long long*)nullptr, reach);
+                       near_map(c, drop_far));
     int rc = run_scan(c, B, n_padded, st, c->d_counters + 2);
     if (rc) return rc;
     hipLaunchKernelGGL(k_grid_scatter, dim3(2048), dim3(256), 0, st, c->rec_buf[b], B.rec_s, c->d_rec_count_buf[b], B.rec_bucket, B.cursor);

@@ -10,7 +10,7 @@ What shards and what does not (DESIGN.md "Multi-GPU"):
     bins the records near its region); 0 = 8x8 pixel tiles dealt round-robin.
   * Photon tracing is independent per photon (streams keyed by global photon index).  Two ways to
     give every rank all records of a pass:
-      exchange="allgather" (default): rank r traces photons [r*M, (r+1)*M) and the packed records
+      exchange="allgather" (default): every batch is a contiguous photon range cut into one block per rank; the packed records
           (1.58 x 80 bytes per photon) are combined with one RCCL all-gather per batch.
       exchange="replicate": every rank traces all photons of the pass itself.  No data-path
           collective, but the tracing does not scale (measured: it is the bottleneck from 2 ranks on).
@@ -50,7 +50,8 @@ class ShardedSppm:
         self.ctx = sppm.SppmContext(cfg, spheres)
         self.image = None
         self._rows = self._all = None
-        self.batch_photons = 1 << 20
+        self.batch_photons = 1 << 20 if world == 1 else (1 << 20) * world  # photons of all ranks per batch
+        self.applied = 0
 
     def describe(self):
         if self.world == 1:
@@ -74,27 +75,39 @@ class ShardedSppm:
     def _photon_pass_allgather(self, i):
         """Rank r traces photons [r*M_rank, (r+1)*M_rank) of the pass in batches; after each batch the
         packed records of all ranks are combined with one RCCL all-gather (padded to the largest
-        count) and every rank applies all of them to its own hitpoints."""
+        count) and every rank applies the ones near its hitpoints (sppm_append_records drops the rest).
+        Batches start small and grow with the photons already applied, like sppm_photon_pass's: the radii
+        are large in the first passes, when a rank keeps most of the records."""
         import torch
         import torch.distributed as dist
         ctx = self.ctx
         dev = ctx.device
-        batch = min(self.M_rank, self.batch_photons)
-        rows_cap = 4 * batch + 4096
-        if self._rows is None or self._rows.shape[0] < rows_cap:
-            self._rows = torch.empty((rows_cap, 10), dtype=torch.float64, device=dev)
-            self._all = torch.empty((self.world, rows_cap, 10), dtype=torch.float64, device=dev)
-        for off in range(0, self.M_rank, batch):
-            n = min(batch, self.M_rank - off)
-            ctx.trace(i, self.rank * self.M_rank + off, n)
+        done = 0  # photons of the pass applied so far, over all ranks
+        while done < self.M:
+            # a batch is a contiguous range of the pass's photons cut into one block per rank, so that batches are
+            # applied in key order and a batch's records are dense in time
+            batch = min(self.batch_photons, max(32768, self.applied // 2))
+            n = min(max(batch // self.world, 1024), (self.M - done) // self.world)
+            rows_cap = 4 * n + 4096
+            if self._rows is None or self._rows.shape[0] < rows_cap:
+                self._rows = torch.empty((rows_cap, 10), dtype=torch.float64, device=dev)
+                self._all = torch.empty((self.world * rows_cap, 10), dtype=torch.float64, device=dev)
+            ctx.trace(i, done + self.rank * n, n)
             cnt = ctx.pack_records(self._rows)
             counts = exchange_counts(cnt, self.world, dev)
-            m = int(max(counts))
+            m = max(1, int(max(counts)))
             # one collective per batch: every rank's rows, padded to the largest count
-            out = self._all[:, :m, :].contiguous() if m < rows_cap else self._all
-            dist.all_gather_into_tensor(out.view(self.world * m, 10), self._rows[:m].contiguous())
+            out = self._all[:self.world * m]
+            dist.all_gather_into_tensor(out, self._rows[:m])
             for r in range(self.world):
-                ctx.append_records(out[r], counts[r], r * self.M_rank + off, r * self.M_rank + off + n)
+                ctx.append_records(out[r * m:(r + 1) * m], counts[r], done + r * n, done + (r + 1) * n)
+            self.applied += n * self.world
+            done += n * self.world
+            # this rank's block of the NEXT batch (of this pass or the next) is traced, and the next eye pass run,
+            # while the gather below works
+            ni, ndone = (i, done) if done < self.M else (i + 1, 0)
+            nn = min(max(min(self.batch_photons, max(32768, self.applied // 2)) // self.world, 1024), (self.M - ndone) // self.world)
+            ctx.look_ahead(ni, ndone + self.rank * nn, nn)
             ctx.gather()
 
     def gather_image(self):

@@ -99,6 +99,9 @@ class SppmContext:
     def trace(self, i, first, count):
         capi.check(self.L.sppm_trace(self.h, i, first, count))
 
+    def look_ahead(self, i, first, count):
+        capi.check(self.L.sppm_look_ahead(self.h, i, first, count))
+
     def gather(self):
         capi.check(self.L.sppm_gather(self.h))
 
