@@ -13,8 +13,11 @@ Nothing is uploaded inside the timed region (scene and state are resident in HBM
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-N > 1 (weak scaling, config 3): a pass has N x photons photons; every rank owns a slice of the
-hitpoints; photon paths are keyed by global photon index so the result does not depend on N.
+N > 1 (weak scaling, config 3): a pass has N x photons photons; every rank owns a compact region of the
+hitpoints (a range of their Morton order), traces its block of every batch and receives the other ranks'
+photon-hit records through one RCCL all-gather per batch; photon paths are keyed by global photon index
+and every hitpoint replays its records in key order, so the result does not depend on N (tested with two
+ranks against one GPU, bit for bit).
 """
 import argparse
 import json
@@ -114,7 +117,9 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         job.step(i)
-    job.ctx.check()   # drains the tracer's stream too
+    if world > 1:
+        job.gather_image()   # the final image on every rank: one all-reduce of the ranks' masked images
+    job.ctx.check()   # drains the look-ahead streams too
     barrier()
     dt = time.perf_counter() - t0
     c1 = job.ctx.counters()

@@ -1,0 +1,34 @@
+"""Worker of tests/test_gpu_distributed.py: one rank of a ShardedSppm run (both ranks share GPU 0; the process
+group is gloo, which carries CUDA tensors through the host -- RCCL needs one GPU per rank)."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    out_dir, exchange, ownership = sys.argv[1], sys.argv[2], int(sys.argv[3])
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from raytracer_amd.parallel import ShardedSppm
+    W, H, M_rank, passes = 96, 64, 24000, 3
+    job = ShardedSppm(W, H, photons_per_rank=M_rank, rank=rank, world=world, exchange=exchange, ownership=ownership)
+    for i in range(passes):
+        job.step(i)
+    job.ctx.check()
+    img = job.gather_image().cpu().numpy()
+    hp = job.ctx.hitpoints()
+    mask = job.ctx.owned_mask().cpu().numpy()
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), image=img, n=hp["n"], r2=hp["r2"], flux=hp["flux"], mask=mask)
+    job.close()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,47 @@
+"""ShardedSppm end to end with two ranks (two processes on one GPU, gloo): the image every rank ends up with and the
+hitpoint state merged by ownership equal a single-GPU run of the same passes bit for bit, for both record exchanges
+and both ownership rules.  RCCL itself needs one GPU per rank and is exercised by bench.py --gpus N on a node."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from raytracer_amd import sppm
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _single(W, H, M, passes):
+    ctx = sppm.SppmContext(sppm.make_config(W, H, photons_per_pass=M))
+    for i in range(passes):
+        ctx.eye_pass(i); ctx.photon_pass(i, M); ctx.end_pass()
+    img = ctx.resolve(passes - 1, M).cpu().numpy()
+    hp = ctx.hitpoints()
+    ctx.check(); ctx.close()
+    return img, hp
+
+
+@pytest.mark.parametrize("exchange,ownership", [("allgather", 1), ("replicate", 0), ("allgather", 0)])
+def test_two_ranks_equal_one_gpu(tmp_path, exchange, ownership):
+    world, W, H, M_rank, passes = 2, 96, 64, 24000, 3
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = 29600 + os.getpid() % 1000 + (0 if exchange == "allgather" else 1) + 2 * ownership
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker_gpu.py"), str(tmp_path), exchange, str(ownership)]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    ref_img, ref = _single(W, H, M_rank * world, passes)
+    got = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    masks = [g["mask"].astype(bool) for g in got]
+    assert (np.sum(masks, axis=0) == 1).all()
+    for g in got:
+        assert (g["image"].view(np.uint64) == ref_img.view(np.uint64)).all(), "image on a rank differs from the single-GPU image"
+    for k in ("n", "r2", "flux"):
+        merged = np.zeros_like(ref[k])
+        for m, g in zip(masks, got):
+            merged[m] = g[k][m]
+        a, b = np.ascontiguousarray(merged), np.ascontiguousarray(ref[k])
+        assert (a.view(np.uint64) == b.view(np.uint64)).all() if a.dtype.kind == "f" else (a == b).all(), k
