@@ -81,6 +81,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    if os.environ.get("SPPM_BENCH_PROGRESS"):  # diagnostics: where every rank is, every 30 s
+        import faulthandler
+        faulthandler.dump_traceback_later(30, repeat=True, file=sys.stderr)
+
     import torch
     import torch.distributed as dist
 
@@ -90,9 +94,15 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             sys.exit("launch N > 1 through torch.distributed.run (one rank per GPU)")
+    # SPPM_BENCH_BACKEND=gloo rehearses the N > 1 path on a box with fewer GPUs than ranks (ranks share devices)
+    backend = os.environ.get("SPPM_BENCH_BACKEND", "nccl")
+    local = local % max(1, torch.cuda.device_count()) if backend != "nccl" else local
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
 
     from raytracer_amd import sppm
     from raytracer_amd.parallel import ShardedSppm
@@ -115,8 +125,12 @@ def main():
     c0 = job.ctx.counters()
     barrier()
     t0 = time.perf_counter()
+    progress = os.environ.get("SPPM_BENCH_PROGRESS")
     for i in range(args.steps):
         job.step(i)
+        if progress and rank == 0:
+            torch.cuda.synchronize()
+            print(f"[bench] pass {i} done at {time.perf_counter() - t0:.3f} s", file=sys.stderr, flush=True)
     if world > 1:
         job.gather_image()   # the final image on every rank: one all-reduce of the ranks' masked images
     job.ctx.check()   # drains the look-ahead streams too
