@@ -116,11 +116,13 @@ def main():
 
     if args.warmup > 0:  # untimed: a scratch render of W passes
         scratch = ShardedSppm(W, H, photons_per_rank=M, rank=rank, world=world)
+        scratch.total_passes = args.warmup
         for i in range(args.warmup):
             scratch.step(i)
         scratch.ctx.check()
         scratch.close()
     job = ShardedSppm(W, H, photons_per_rank=M, rank=rank, world=world)
+    job.total_passes = args.steps
     job.ctx.set_timing(True)
     c0 = job.ctx.counters()
     barrier()

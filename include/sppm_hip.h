@@ -141,6 +141,12 @@ int sppm_trace(sppm_ctx* ctx, int32_t pass, int64_t first, int64_t count);
  * pass, its eye pass (adopted by sppm_eye_pass(pass)).  Photon paths do not depend on hitpoints and eye paths do
  * not depend on photons, so results do not change; work that is not asked for afterwards is dropped. */
 int sppm_look_ahead(sppm_ctx* ctx, int32_t pass, int64_t first, int64_t count);
+/* sppm_look_ahead plus, behind the trace on the same internal stream, sppm_pack_records of what it traced into
+ * d_rows (device, cap_rows x 10 doubles): this rank's rows of the NEXT batch become ready while the context's stream
+ * is busy, so the exchange between ranks can overlap the gather.  sppm_rows_ready blocks the host until they are
+ * there and returns their number; d_rows may then be read on any stream.  No counterpart in the reference. */
+int sppm_look_ahead_rows(sppm_ctx* ctx, int32_t pass, int64_t first, int64_t count, double* d_rows, int64_t cap_rows);
+int sppm_rows_ready(sppm_ctx* ctx, int64_t* n);
 int sppm_gather(sppm_ctx* ctx);
 int sppm_pack_records(sppm_ctx* ctx, double* d_rows, int64_t cap_rows, int64_t* n);
 int sppm_append_records(sppm_ctx* ctx, const double* d_rows, int64_t n, int64_t photon_first, int64_t photon_end);

@@ -955,6 +955,7 @@ struct sppm_ctx {
     hipStream_t eye_stream; hipEvent_t ev_eye_done, ev_eye_go;
     struct { int valid, pass; } pre_eye;  // an eye pass computed ahead of its call
     int last_eye_pass;
+    unsigned long long *d_rows_n, *h_rows_n; hipEvent_t ev_rows; int rows_pending; int64_t rows_cap;  // sppm_look_ahead_rows
     RecArrays rec_u, rec_s;  // unsorted (traced / received), sorted by bucket
     unsigned long long* d_rec_count;
     unsigned long long* d_counters;  // 8: [0] rays [3] candidates [4] updates [5] selected [6] rounds [7] live tile launches
@@ -1169,6 +1170,11 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
         TRY(dev_alloc(c, &B.block_sum, (size_t)nb / SCAN_BLOCK + 1)); TRY(dev_alloc(c, &B.total, 1));
     }
     if (!c->gather_mode) c->bins[1] = c->bins[0];
+    c->h_rows_n = nullptr; c->ev_rows = nullptr; c->rows_pending = 0; c->rows_cap = 0;
+    TRY(dev_alloc(c, &c->d_rows_n, 1));
+    if (hipHostMalloc((void**)&c->h_rows_n, sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess || hipEventCreateWithFlags(&c->ev_rows, hipEventDisableTiming) != hipSuccess) {
+        sppm_destroy(c); return fail(SPPM_ERR_HIP, "pinned memory / event for the packed rows");
+    }
     c->h_stat = nullptr; c->ev_stat[0] = c->ev_stat[1] = nullptr; c->stat_w = 0; c->stat_n = 0; c->gs.valid = 0; c->snap_prev_valid = 0; c->gather_j = 0;
     if (hipHostMalloc((void**)&c->h_stat, 2 * sizeof(sppm_ctx::StatSlot), hipHostMallocDefault) != hipSuccess) { sppm_destroy(c); return fail(SPPM_ERR_HIP, "pinned host memory for the tile statistics"); }
     for (int b = 0; b < 2; b++)
@@ -1236,6 +1242,8 @@ extern "C" int sppm_destroy(sppm_ctx* c)
     for (auto& e : c->ev_trace) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (void* p : c->allocs) hipFree(p);
     if (c->h_stat) hipHostFree(c->h_stat);
+    if (c->h_rows_n) hipHostFree(c->h_rows_n);
+    if (c->ev_rows) hipEventDestroy(c->ev_rows);
     for (int b = 0; b < 2; b++) if (c->ev_stat[b]) hipEventDestroy(c->ev_stat[b]);
     if (c->d_u_eye) hipFree(c->d_u_eye);
     if (c->d_u_ph) hipFree(c->d_u_ph);
@@ -1521,6 +1529,42 @@ extern "C" int sppm_look_ahead(sppm_ctx* c, int32_t pass, int64_t first, int64_t
     HIPCHK(hipEventRecord(c->ev_traced[nb], c->trace_stream));
     c->pre.valid = 1; c->pre.buf = nb; c->pre.pass = pass; c->pre.first = first; c->pre.count = count;
     if (pass == c->last_eye_pass + 1) { rc = eye_prefetch(c, pass); if (rc) return rc; }
+    return SPPM_OK;
+}
+
+// sppm_look_ahead followed, on the tracer's stream, by the packing of what was traced into d_rows: the rows
+// of this rank's block of the NEXT batch get ready while the context's stream is busy with the gather of this
+// one, and the caller can exchange them in the meantime.  sppm_rows_ready waits for them (host side).
+extern "C" int sppm_look_ahead_rows(sppm_ctx* c, int32_t pass, int64_t first, int64_t count, double* d_rows, int64_t cap_rows)
+{
+    if (!c || !d_rows || cap_rows < 0) return fail(SPPM_ERR_INVALID, "sppm_look_ahead_rows: bad argument");
+    if (c->sampler == 1) return fail(SPPM_ERR_STATE, "sppm_look_ahead_rows: the sequential reference stream cannot run ahead");
+    c->rows_pending = 0;
+    int rc = sppm_look_ahead(c, pass, first, count);
+    if (rc) return rc;
+    hipStream_t ts = c->trace_stream;
+    const int nb = count > 0 ? c->pre.buf : 1 - c->cur;
+    HIPCHK(hipMemsetAsync(c->d_rows_n, 0, sizeof(unsigned long long), ts));
+    if (count > 0) {
+        hipLaunchKernelGGL(k_pack_records, dim3(nblk(c->rec_buf[nb].cap, 4 * WAVE_ROWS)), dim3(256), 0, ts, c->rec_buf[nb], c->d_rec_count_buf[nb], d_rows, cap_rows, c->d_rows_n);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemsetAsync(c->d_rec_count_buf[nb], 0, sizeof(unsigned long long), ts));  // the records live in the rows now
+        c->pre.valid = 0;
+    }
+    HIPCHK(hipMemcpyAsync(c->h_rows_n, c->d_rows_n, sizeof(unsigned long long), hipMemcpyDeviceToHost, ts));
+    HIPCHK(hipEventRecord(c->ev_rows, ts));
+    c->rows_pending = 1; c->rows_cap = cap_rows;
+    return SPPM_OK;
+}
+
+extern "C" int sppm_rows_ready(sppm_ctx* c, int64_t* n)
+{
+    if (!c || !n) return fail(SPPM_ERR_INVALID, "sppm_rows_ready: null argument");
+    if (!c->rows_pending) return fail(SPPM_ERR_STATE, "sppm_rows_ready: no sppm_look_ahead_rows is outstanding");
+    HIPCHK(hipEventSynchronize(c->ev_rows));
+    c->rows_pending = 0;
+    *n = (int64_t)*c->h_rows_n;
+    if (*n > c->rows_cap) return fail(SPPM_ERR_OVERFLOW, "sppm_rows_ready: the row buffer was too small (n holds the count needed)");
     return SPPM_OK;
 }
 

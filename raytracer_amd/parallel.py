@@ -49,7 +49,8 @@ class ShardedSppm:
         cfg = sppm.make_config(width, height, photons_per_pass=self.M, tile_first=rank, tile_stride=world, ownership=ownership, **cfg_kw)
         self.ctx = sppm.SppmContext(cfg, spheres)
         self.image = None
-        self._rows = self._all = None
+        self._rows = self._all = self._side = self._next = None
+        self.total_passes = None   # if set, nothing is started ahead for passes >= total_passes
         self.batch_photons = 1 << 20 if world == 1 else (1 << 20) * world  # photons of all ranks per batch
         self.applied = 0
 
@@ -72,43 +73,68 @@ class ShardedSppm:
             self.image = ctx.resolve(i, self.M)
         return self.image
 
-    def _photon_pass_allgather(self, i):
-        """Rank r traces photons [r*M_rank, (r+1)*M_rank) of the pass in batches; after each batch the
-        packed records of all ranks are combined with one RCCL all-gather (padded to the largest
-        count) and every rank applies the ones near its hitpoints (sppm_append_records drops the rest).
-        Batches start small and grow with the photons already applied, like sppm_photon_pass's: the radii
-        are large in the first passes, when a rank keeps most of the records."""
+    # ---- all-gather exchange, pipelined --------------------------------------------------------------------
+    def _batch_size(self, done):
+        """photons per rank of the batch that starts at photon `done` of a pass (same rule on every rank)"""
+        batch = min(self.batch_photons, max(32768, self.applied // 2))
+        return min(max(batch // self.world, 1024), (self.M - done) // self.world)
+
+    def _buffers(self):
+        import torch
+        if self._rows is None:
+            cap = 4 * (self.batch_photons // self.world) + 4096
+            dev = self.ctx.device
+            self._rows = [torch.empty((cap, 10), dtype=torch.float64, device=dev) for _ in range(2)]
+            self._all = [torch.empty((self.world * cap, 10), dtype=torch.float64, device=dev) for _ in range(2)]
+            self._side = torch.cuda.Stream(device=dev)
+
+    def _start_block(self, i, done, n, buf):
+        """trace this rank's block of the batch (and the eye pass of pass i, if it is the next one) on the context's
+        look-ahead streams and pack it into rows[buf]"""
+        self.ctx.look_ahead_rows(i, done + self.rank * n, n, self._rows[buf])
+
+    def _exchange(self, i, done, n, buf):
+        """wait for the block's rows, then one all-gather (padded to the largest count) on the side stream"""
         import torch
         import torch.distributed as dist
-        ctx = self.ctx
-        dev = ctx.device
-        done = 0  # photons of the pass applied so far, over all ranks
-        while done < self.M:
-            # a batch is a contiguous range of the pass's photons cut into one block per rank, so that batches are
-            # applied in key order and a batch's records are dense in time
-            batch = min(self.batch_photons, max(32768, self.applied // 2))
-            n = min(max(batch // self.world, 1024), (self.M - done) // self.world)
-            rows_cap = 4 * n + 4096
-            if self._rows is None or self._rows.shape[0] < rows_cap:
-                self._rows = torch.empty((rows_cap, 10), dtype=torch.float64, device=dev)
-                self._all = torch.empty((self.world * rows_cap, 10), dtype=torch.float64, device=dev)
-            ctx.trace(i, done + self.rank * n, n)
-            cnt = ctx.pack_records(self._rows)
-            counts = exchange_counts(cnt, self.world, dev)
+        cnt = self.ctx.rows_ready()
+        with torch.cuda.stream(self._side):
+            counts = exchange_counts(cnt, self.world, self.ctx.device)
             m = max(1, int(max(counts)))
-            # one collective per batch: every rank's rows, padded to the largest count
-            out = self._all[:self.world * m]
-            dist.all_gather_into_tensor(out, self._rows[:m])
+            dist.all_gather_into_tensor(self._all[buf][:self.world * m], self._rows[buf][:m])
+        self._next = dict(key=(i, done, n), counts=counts, m=m, buf=buf)
+
+    def _photon_pass_allgather(self, i):
+        """Every batch is a contiguous range of the pass's photons cut into one block per rank (so batches are applied in
+        key order and a batch's records are dense in time).  A rank traces its block, the packed records of all ranks
+        are combined with one RCCL all-gather, and every rank applies the ones near its hitpoints
+        (sppm_append_records drops the rest).  The block of the NEXT batch is traced and exchanged while the gather
+        of this one runs.  Batches start small and grow with the photons already applied, like sppm_photon_pass's:
+        the radii are large in the first passes, when a rank keeps most of the records."""
+        import torch
+        ctx = self.ctx
+        self._buffers()
+        done = 0
+        while done < self.M:
+            n = self._batch_size(done)
+            if self._next is None or self._next["key"] != (i, done, n):   # nothing was started ahead (first batch)
+                self._start_block(i, done, n, 0)
+                self._exchange(i, done, n, 0)
+            ex, self._next = self._next, None
+            torch.cuda.current_stream().wait_stream(self._side)
+            rows, m = self._all[ex["buf"]], ex["m"]
             for r in range(self.world):
-                ctx.append_records(out[r * m:(r + 1) * m], counts[r], done + r * n, done + (r + 1) * n)
+                ctx.append_records(rows[r * m:(r + 1) * m], ex["counts"][r], done + r * n, done + (r + 1) * n)
             self.applied += n * self.world
             done += n * self.world
-            # this rank's block of the NEXT batch (of this pass or the next) is traced, and the next eye pass run,
-            # while the gather below works
             ni, ndone = (i, done) if done < self.M else (i + 1, 0)
-            nn = min(max(min(self.batch_photons, max(32768, self.applied // 2)) // self.world, 1024), (self.M - ndone) // self.world)
-            ctx.look_ahead(ni, ndone + self.rank * nn, nn)
+            ahead = self.total_passes is None or ni < self.total_passes
+            if ahead:
+                nn = self._batch_size(ndone)
+                self._start_block(ni, ndone, nn, 1 - ex["buf"])
             ctx.gather()
+            if ahead:
+                self._exchange(ni, ndone, nn, 1 - ex["buf"])   # overlaps the gather just enqueued
 
     def gather_image(self):
         """Full image on every rank: a rank's resolve is valid on the hitpoints it owns; the others are zeroed and

@@ -102,6 +102,14 @@ class SppmContext:
     def look_ahead(self, i, first, count):
         capi.check(self.L.sppm_look_ahead(self.h, i, first, count))
 
+    def look_ahead_rows(self, i, first, count, rows):
+        capi.check(self.L.sppm_look_ahead_rows(self.h, i, first, count, rows.data_ptr(), rows.shape[0]))
+
+    def rows_ready(self):
+        n = C.c_int64()
+        capi.check(self.L.sppm_rows_ready(self.h, C.byref(n)))
+        return n.value
+
     def gather(self):
         capi.check(self.L.sppm_gather(self.h))
 
