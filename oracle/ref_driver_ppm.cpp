@@ -12,7 +12,7 @@
 // pass (as for sppm2.h).  render() also writes image files every few photons and offers no tap.
 // Determinism: std::random_device::_M_getval is interposed to return a counter (seed of every mt19937).
 //
-// usage: ref_driver_ppm outdir W H photons traced gather_r2 gather_k [seed_eye seed_photon]
+// usage: ref_driver_ppm outdir W H photons traced gather_r2 gather_k [seed_eye seed_photon supersamples]
 #include <algorithm>
 #include <climits>
 #include <cmath>
@@ -58,7 +58,7 @@ static HpKey key_of(const ppm::ProgressiveIntersection& p) { return HpKey(p.inde
 
 int main(int argc, char** argv)
 {
-    if (argc < 8) { fprintf(stderr, "usage: %s outdir W H photons traced gather_r2 gather_k [seed_eye seed_photon]\n", argv[0]); return 2; }
+    if (argc < 8) { fprintf(stderr, "usage: %s outdir W H photons traced gather_r2 gather_k [seed_eye seed_photon supersamples]\n", argv[0]); return 2; }
     g_out = argv[1];
     const int W = atoi(argv[2]), H = atoi(argv[3]), P = W * H;
     const int photon_num = atoi(argv[4]), traced = atoi(argv[5]);
@@ -66,7 +66,7 @@ int main(int argc, char** argv)
     const int gather_k = atoi(argv[7]);
     const unsigned seed_eye = argc > 8 ? (unsigned)strtoul(argv[8], 0, 10) : 1000u;
     const unsigned seed_photon = argc > 9 ? (unsigned)strtoul(argv[9], 0, 10) : 2000u;
-    const int samples = 1, supersamples = 1, spp = 1;
+    const int samples = 1, supersamples = argc > 10 ? atoi(argv[10]) : 1, spp = samples * supersamples * supersamples;  // samples > 1 repeats one ray: identical hitpoints
 
     std::streambuf* cout_buf = std::cout.rdbuf();
     std::ofstream devnull("/dev/null");
@@ -81,6 +81,7 @@ int main(int argc, char** argv)
     const Vec screen_y = normalize(cross(screen_x, camera_dir)) * screen_height;
     const Vec screen_center = camera_position + camera_dir * screen_dist;
 
+    ppm::InitialRadius = gather_r2;  // as its caller does, src/main.cpp:76-77
     ppm::PointMap point_map;
     g_seed_counter = seed_eye;
     ValueSampler<double> eye_sampler(0, 1);

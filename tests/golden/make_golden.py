@@ -81,6 +81,33 @@ def run(tag, w, h, photons, passes, traced, r2, k, seed_eye, seed_photon, full):
         print(f"wrote {path}: {os.path.getsize(path) / 1024:.0f} KiB")
 
 
+def run_ppm(tag, w, h, photons, traced, r2, k, seed_eye, seed_photon, supersamples):
+    """Classic progressive photon mapping (src/progressive_photonmapping.h) through oracle/ref_driver_ppm.cpp."""
+    exe = os.path.join(ORACLE, "_ref", "ref_driver_ppm")
+    with tempfile.TemporaryDirectory() as d:
+        subprocess.check_call([exe, d, str(w), str(h), str(photons), str(traced), repr(float(r2)), str(k),
+                               str(seed_eye), str(seed_photon), str(supersamples)])
+        P = w * h
+        hp_i = rd(d, "ppm_hp_i.bin", np.int32).reshape(-1, 2)
+        out = dict(meta=np.array([w, h, photons, traced, k, seed_eye, seed_photon, supersamples], np.int64),
+                   gather_r2=np.array([r2], np.float64),
+                   hp_pix=hp_i[:, 0].copy(), hp_obj=hp_i[:, 1].astype(np.int8),
+                   hp_f=rd(d, "ppm_hp_f.bin", np.float64).reshape(-1, 11),
+                   eye_words=rd(d, "ppm_eye_words.bin", np.uint64),
+                   kd_order=rd(d, "ppm_kd_order.bin", np.int32),
+                   ph_words=rd(d, "ppm_ph_words.bin", np.int32),
+                   acc_off=rd(d, "ppm_acc_off.bin", np.int32), acc_hp=rd(d, "ppm_acc_hp.bin", np.int32),
+                   acc_cnt=rd(d, "ppm_acc_cnt.bin", np.int32).astype(np.int8),
+                   state_n=rd(d, "ppm_state_n.bin", np.int32),
+                   state_f=rd(d, "ppm_state_f.bin", np.float64).reshape(-1, 4),
+                   image=rd(d, "ppm_image.bin", np.float64).reshape(P, 3),
+                   final_hdr=np.frombuffer(open(os.path.join(d, "ppm_final.hdr"), "rb").read(), np.uint8),
+                   final_ppm_sha256=np.frombuffer(hashlib.sha256(open(os.path.join(d, "ppm_final.ppm"), "rb").read()).digest(), np.uint8))
+        path = os.path.join(HERE, f"ref_ppm_{tag}.npz")
+        np.savez_compressed(path, **out)
+        print(f"wrote {path}: {os.path.getsize(path) / 1024:.0f} KiB, {len(hp_i)} hitpoints")
+
+
 def main():
     if not os.path.isdir("/root/reference/src"):
         sys.exit("the reference is not present here; fixtures can only be regenerated in the build container")
@@ -89,6 +116,9 @@ def main():
     run("64x48", 64, 48, 20000, 3, 4096, 25.0, 100000, 1000, 2000, True)
     run("64x48_r5", 64, 48, 20000, 2, 1024, 5.0, 10000, 31, 77, False)   # main.cpp:76-80's r=5, K=10000
     run("320x240", 320, 240, 200000, 2, 1024, 25.0, 100000, 1000, 2000, False)
+    # tag, W, H, photons, per-photon-traced, search r^2 (= InitialRadius, main.cpp:76-77), K cap, seeds, supersamples
+    run_ppm("64x48", 64, 48, 20000, 4096, 25.0, 100000, 1000, 2000, 1)
+    run_ppm("48x36_ss2_r5", 48, 36, 30000, 2048, 5.0, 100000, 31, 77, 2)
 
 
 if __name__ == "__main__":

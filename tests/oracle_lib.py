@@ -66,6 +66,14 @@ def lib():
     L.orc_hdr_file.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64]
     L.orc_ppm_file.restype = C.c_int64
     L.orc_ppm_file.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64]
+    L.orc_ppm_create.restype = C.c_void_p
+    L.orc_ppm_create.argtypes = [C.POINTER(OrcParams), C.POINTER(OrcSphere), C.c_int, C.c_int]
+    L.orc_ppm_eye_pass.restype = C.c_int
+    L.orc_ppm_eye_pass.argtypes = [C.c_void_p]
+    L.orc_ppm_kd_order.restype = C.c_int
+    L.orc_ppm_kd_order.argtypes = [C.c_void_p, C.c_void_p]
+    L.orc_ppm_get_state.argtypes = [C.c_void_p] + [C.c_void_p] * 6
+    L.orc_ppm_resolve.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
     _LIB = L
     return L
 
@@ -171,6 +179,49 @@ class Oracle:
         a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
         self.L.orc_counters(self.h, C.byref(a), C.byref(b), C.byref(c))
         return dict(eye_draws=a.value, updates=b.value, rays=c.value)
+
+
+class PpmOracle(Oracle):
+    """Classic progressive photon mapping (src/progressive_photonmapping.h): a LIST of hitpoints in creation
+    order, several per pixel; photon_pass(0, count, ...) of the base class runs its photons (acc_pix of the tap
+    then holds hitpoint ids)."""
+
+    def __init__(self, params, spheres, cap=None):
+        self.L = lib()
+        self.params = params
+        self.spheres = spheres
+        self.P = params.width * params.height
+        self.cap = cap or 16 * self.P * params.samples * params.supersamples ** 2
+        self.h = self.L.orc_ppm_create(C.byref(params), spheres, len(spheres), self.cap)
+        self.nh = 0
+
+    def eye_pass(self, i=0):
+        assert i == 0, "classic PPM traces its hitpoints once"
+        self.nh = self.L.orc_ppm_eye_pass(self.h)
+        assert self.nh >= 0, "hitpoint capacity too small"
+        return self.nh
+
+    def kd_order(self):
+        o = np.zeros(self.nh, np.int32)
+        fallback = self.L.orc_ppm_kd_order(self.h, _p(o))
+        assert fallback == 0, "std::sort's heapsort fallback was reached: the vector order is not pinned"
+        return o
+
+    def state(self):
+        n = self.nh
+        s = dict(pix=np.zeros(n, np.int32), obj=np.zeros(n, np.int32), hp_f=np.zeros((n, 11)), r2=np.zeros(n),
+                 n=np.zeros(n, np.int32), flux=np.zeros((n, 3)))
+        self.L.orc_ppm_get_state(self.h, _p(s["pix"]), _p(s["obj"]), _p(s["hp_f"]), _p(s["r2"]), _p(s["n"]), _p(s["flux"]))
+        return s
+
+    def end_pass(self):
+        pass
+
+    def resolve(self, photon_num, order=1):
+        """order 0: the reference's kd-sorted vector order; 1: creation order (per-pixel sums on the GPU)."""
+        img = np.zeros((self.P, 3))
+        self.L.orc_ppm_resolve(self.h, photon_num, order, _p(img))
+        return img
 
 
 def mt_samples(seed, n):

@@ -79,3 +79,45 @@ def test_sppm_passes(golden, tag):
     else:
         import hashlib
         assert hashlib.sha256(ol.ppm_file(img, w, h)).digest() == g["final_ppm_sha256"].tobytes()
+
+
+@pytest.mark.parametrize("tag", ["64x48", "48x36_ss2_r5"])
+def test_classic_ppm(golden, tag):
+    """src/progressive_photonmapping.h: create_point's hitpoint list, the kd-sorted order render() sums in, the
+    photons' accepted hitpoint sets, radii/counts/flux after all photons, the image and the .hdr bytes."""
+    g = golden("ppm_" + tag)
+    w, h, photons, traced, k, se, sp, ss = [int(x) for x in g["meta"]]
+    r2 = float(g["gather_r2"][0])
+    p = ol.make_params(w, h, supersamples=ss, sampler=0, math=0, gather_radius2=r2, initial_radius2=r2, gather_max=k,
+                       seed_eye=se, seed_photon=sp, photons_per_pass=photons)
+    o = ol.PpmOracle(p, ol.make_spheres(CORNELL_SPHERES))
+    nh = o.eye_pass()
+    assert nh == len(g["hp_pix"]), "number of hitpoints"
+    s = o.state()
+    _bits(s["pix"], g["hp_pix"], "hitpoint image indices, creation order")
+    _bits(s["obj"].astype(np.int8), g["hp_obj"], "hitpoint object ids")
+    _bits(s["hp_f"], g["hp_f"], "hitpoint records (distance, position, normal, weight, emission)")
+    assert o.counters()["eye_draws"] * 2 == int(g["eye_words"][0]), "eye stream position"
+    _bits(o.kd_order(), g["kd_order"], "CreateKDtree's vector order (std::sort's tie order included)")
+    t = o.photon_pass(0, photons, tap=True, acc_cap=60_000_000)
+    s = o.state()
+    _bits(s["n"], g["state_n"], "photon counts")
+    _bits(s["r2"], g["state_f"][:, 0], "radii")
+    _bits(s["flux"], g["state_f"][:, 1:], "accumulated flux")
+    nw = len(g["ph_words"])
+    _bits(t["draws"][:nw] * 2, g["ph_words"], "engine words per photon")
+    ph = t["rec_photon"][t["acc_rec"]]
+    sel = ph < nw
+    order = np.lexsort((t["acc_pix"][sel], ph[sel]))
+    pairs, cnt = np.unique(np.stack([ph[sel][order], t["acc_pix"][sel][order]], 1), axis=0, return_counts=True)
+    _bits(pairs[:, 0], np.repeat(np.arange(nw), np.diff(g["acc_off"])), "accepted sets (photon)")
+    _bits(pairs[:, 1], g["acc_hp"], "accepted sets (hitpoint id)")
+    _bits(cnt.astype(np.int8), g["acc_cnt"], "accepted multiplicity")
+    img = o.resolve(photons, order=0)
+    _bits(img, g["image"], "image, summed in the reference's vector order")
+    assert ol.hdr_file(img, w, h) == g["final_hdr"].tobytes(), "save_hdr_file bytes"
+    import hashlib
+    assert hashlib.sha256(ol.ppm_file(img, w, h)).digest() == g["final_ppm_sha256"].tobytes()
+    # creation-order sums (what the GPU path does) differ only by the rounding of a few-term sum
+    img1 = o.resolve(photons, order=1)
+    assert np.abs(img1 - img).max() <= 4e-16 * np.abs(img).max()
