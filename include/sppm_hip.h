@@ -87,7 +87,18 @@ typedef struct sppm_config {
                                    same partition on every rank without an exchange (the eye pass is replicated).
                                    Tiles stay as dense as on one GPU and records far from the rank's hitpoints are
                                    dropped when a batch is binned.  Results are identical either way. */
-    int32_t reserved_[1];
+    int32_t algorithm;       /* 0: stochastic progressive photon mapping, StochasticPpm<W,H>::render (src/sppm2.h) -- default.
+                                1: classic progressive photon mapping, photonmap::progressive::render
+                                   (src/progressive_photonmapping.h:709-821; what src/main.cpp:87 runs): ONE eye pass
+                                   whose recursion (create_point, :496-615) leaves a LIST of hitpoints, several per
+                                   pixel; photons deposit from their first diffuse hit on (:326,339,344) with the
+                                   photon surface's colour and no hitpoint weight (:385-387); the image sums every
+                                   pixel's hitpoints (:807-813).  sppm_create counts the list (sppm_hitpoint_count);
+                                   then sppm_eye_pass(ctx, 0), sppm_photon_pass(ctx, 0, first, count) for any split of
+                                   the photons [0, photons_per_pass), sppm_resolve(ctx, 0, photon_num, image).
+                                   initial_radius2 is progressive::InitialRadius (:32, set by src/main.cpp:77).
+                                   update_rule 0, one GPU.  With sampler 1 the eye pass reads the reference's one
+                                   sequential stream (:760) and the photons its second one (:619). */
 } sppm_config;
 
 typedef struct sppm_ctx sppm_ctx;
@@ -166,7 +177,15 @@ int sppm_save_ppm_file(const char* filename, const double* h_image, int32_t widt
 /* Waits for the context's stream and reports a deferred device-side error (record overflow, K cap). */
 int sppm_check(sppm_ctx* ctx);
 
-/* Taps for parity tests.  Host output arrays, any may be NULL.
+/* Number of hitpoint slots: width*height for algorithm 0 (one per image index); the length of the
+ * hitpoint list for algorithm 1 (point_map.GetData().size() after the loops of
+ * src/progressive_photonmapping.h:760-793), known from sppm_create on. */
+int sppm_hitpoint_count(sppm_ctx* ctx, int64_t* n);
+/* algorithm 1: ProgressiveIntersection::index of every hitpoint, in creation order: h_pix[sppm_hitpoint_count]. */
+int sppm_download_hitpoint_pixels(sppm_ctx* ctx, int32_t* h_pix);
+
+/* Taps for parity tests.  Host output arrays, any may be NULL.  P = sppm_hitpoint_count; for algorithm 1
+ * the index is the hitpoint's place in creation order, the three weights are the scalar weight, ld is 0.
  * Hitpoints by image index: valid[P], obj[P] (-1 if none), hp_f[P][10] = distance, position,
  * normal, weight; r2[P]; n[P]; flux[P][3]; ld[P][3]. */
 int sppm_download_hitpoints(sppm_ctx* ctx, int32_t* h_valid, int32_t* h_obj, double* h_hp_f, double* h_r2,

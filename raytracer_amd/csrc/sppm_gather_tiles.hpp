@@ -34,6 +34,7 @@ struct TileParams {
     TileGrid g;
     double gather_r2, alpha;
     int rule;
+    int unit_weight;       // classic PPM: hitpoint weight and colour are not part of the flux update
     const int32_t* order;  // this rank's image indices, sorted along a Morton curve of the hitpoint positions
     int n_pix, n_owned;    // entries of order[]; virtual tiles = ceil(n_pix / 64)
     double cluster_d;      // lanes farther than this (max norm) from a tile's seed lane are replayed separately
@@ -426,8 +427,9 @@ __global__ void __launch_bounds__(256) GATHER_WAVES_ATTR k_gather_tiles(HpArrays
     if (live) {
         hpos = mk(hp.pos[p], hp.pos[P + p], hp.pos[2 * P + p]);
         hn = mk(hp.nrm[p], hp.nrm[P + p], hp.nrm[2 * P + p]);
-        hw = mk(hp.w[p], hp.w[P + p], hp.w[2 * P + p]);
-        hcol = ld3(sc.sp[hp.obj[p]].color);
+        // classic PPM (tp.unit_weight): the record's flux is applied as it is, src/progressive_photonmapping.h:385-387
+        hw = tp.unit_weight ? mk(1, 1, 1) : mk(hp.w[p], hp.w[P + p], hp.w[2 * P + p]);
+        hcol = tp.unit_weight ? mk(1, 1, 1) : ld3(sc.sp[hp.obj[p]].color);
         r2 = hp.r2[p];
         if (tp.rule == 0) { n = hp.n[p]; acc = mk(hp.flux[p], hp.flux[P + p], hp.flux[2 * P + p]); }
         else { madd = hp.madd[p]; acc = mk(hp.phi[p], hp.phi[P + p], hp.phi[2 * P + p]); }

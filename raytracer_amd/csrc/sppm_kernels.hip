@@ -72,6 +72,9 @@ struct EyeParams {
     Camera cam; int W, H, samples, supersamples; int pass; uint32_t seed_eye; double initial_r2; int double_nee;
     // reference-stream mode only
     const double* u; int64_t u_len; uint32_t* cnt; unsigned long long* off; unsigned long long* total;
+    // classic progressive photon mapping only: hitpoints per pixel (out) / first hitpoint slot per pixel (in),
+    // both indexed by the pixel's place t in the render order
+    uint32_t* hcnt; const long long* hoff;
 };
 
 // One pixel of an eye pass: the sy/sx/s loops of src/sppm2.h:628-643 around create_point_loop
@@ -204,6 +207,145 @@ __global__ void __launch_bounds__(256) k_eye_pass(DevScene sc, EyeParams ep, HpA
     if ((threadIdx.x & 63) == 0 && rays) atomicAdd(&counters[0], (unsigned long long)rays);
 }
 
+// ---- classic progressive photon mapping: the eye pass ------------------------------------------------------
+// create_point, src/progressive_photonmapping.h:496-615, for one pixel: the sy/sx/s loops of render()
+// (:769-791) around a recursion that leaves a hitpoint at EVERY diffuse surface it reaches.  Glass follows
+// both branches while depth <= 2 (reflection first, :606-609) and one branch chosen by a draw afterwards
+// (:586-603); roulette from depth > kDepth (:519-524); the weight is a scalar.  The recursion is a loop with
+// a stack: only the refracted branches of depths 0, 1 and 2 can be pending at the same time, and the draws
+// are consumed in the reference's depth-first order.  Hitpoints go to slots base, base+1, ... in creation
+// order (COMMIT); the function returns how many the pixel has.
+#define PPM_DEPTH_LIMIT 64  // kDepthLimit, src/radiance.h:18
+template <class RNG, bool COMMIT>
+__device__ __forceinline__ int ppm_pixel(const DevScene& sc, const EyeParams& ep, const HpArrays& out, int t, long long base, RNG& rng, uint32_t& rays)
+{
+    const int P = out.P;
+    const int x = t % ep.W, y = t / ep.W;
+    int count = 0;
+    for (int sy = 0; sy < ep.supersamples; sy++)
+        for (int sx = 0; sx < ep.supersamples; sx++)
+            for (int s = 0; s < ep.samples; s++) {
+                d3 org, dir;
+                camera_ray(ep.cam, x, y, sx, sy, org, dir);
+                double weight = 1.0;
+                int depth = 0;
+                d3 st_org[3], st_dir[3]; double st_w[3]; int st_depth[3];
+                int sp = 0;
+                for (;;) {  // one create_point call per trip
+                    bool ended = true;
+                    Hit is;
+                    rays++;
+                    if (intersect_scene(sc.sp, sc.ns, org, dir, is)) {
+                        const sppm_sphere* obj = &sc.sp[is.object_id];
+                        const d3 color = ld3(obj->color);
+                        const int type = obj->reflection_type;
+                        const d3 on = dot(is.normal, dir) < 0.0 ? is.normal : is.normal * -1.0;
+                        double rr = max3(color);
+                        if (depth > PPM_DEPTH_LIMIT) rr *= ldexp(1.0, -(depth - PPM_DEPTH_LIMIT));  // std::pow(0.5, depth - kDepthLimit)
+                        bool alive = true;
+                        if (depth > SPPM_KDEPTH) {
+                            rng.decision();
+                            if (rng.next01() >= rr) alive = false;
+                        } else
+                            rr = 1.0;
+                        if (alive) {
+                            if (type == SPPM_DIFFUSE) {  // :529-534
+                                if constexpr (COMMIT) {
+                                    const long long h = base + count;
+                                    const double w = weight / rr;
+                                    out.pos[h] = is.position.x; out.pos[P + h] = is.position.y; out.pos[2 * (long long)P + h] = is.position.z;
+                                    out.nrm[h] = is.normal.x; out.nrm[P + h] = is.normal.y; out.nrm[2 * (long long)P + h] = is.normal.z;
+                                    out.w[h] = w; out.w[P + h] = w; out.w[2 * (long long)P + h] = w;
+                                    out.obj[h] = is.object_id; out.dist[h] = is.distance; out.valid[h] = 1;
+                                    out.r2[h] = ep.initial_r2;
+                                    out.n[h] = 0;  // the constructor drops photon_count (:46-55); its call site passes 0
+                                    out.flux[h] = 0.0; out.flux[P + h] = 0.0; out.flux[2 * (long long)P + h] = 0.0;
+                                }
+                                count++;
+                            } else if (type == SPPM_SPECULAR) {  // :537-544
+                                org = is.position;
+                                dir = reflect_dir(dir, is.normal);
+                                weight = weight / rr;
+                                depth++;
+                                ended = false;
+                            } else {
+                                const d3 rdir = reflect_dir(dir, is.normal);
+                                bool into; double nnt, Re; d3 tdir;
+                                org = is.position;
+                                if (!glass(dir, is.normal, on, false, into, nnt, tdir, Re)) {  // :561-566
+                                    dir = rdir;
+                                    weight = weight / rr;
+                                } else {
+                                    const double nnt2 = nnt * nnt;  // std::pow(nnt, 2.0)
+                                    const double Tr = (1.0 - Re) * nnt2;
+                                    const double prob = 0.25 + 0.5 * Re;
+                                    if (depth > 2) {
+                                        rng.decision();
+                                        if (rng.next01() < prob) { dir = rdir; weight = weight * Re / (prob * rr); }
+                                        else { dir = tdir; weight = weight * Tr / ((1.0 - prob) * rr); }
+                                    } else {  // both: the reflected branch now, the refracted one once that subtree is done
+                                        st_org[sp] = org; st_dir[sp] = tdir; st_w[sp] = weight * Tr / rr; st_depth[sp] = depth + 1;
+                                        sp++;
+                                        dir = rdir;
+                                        weight = weight * Re / rr;
+                                    }
+                                }
+                                depth++;
+                                ended = false;
+                            }
+                        }
+                    }
+                    if (rng.stop()) return count;  // sequential-stream samplers only
+                    if (ended) {
+                        if (sp == 0) break;
+                        sp--;
+                        org = st_org[sp]; dir = st_dir[sp]; weight = st_w[sp]; depth = st_depth[sp];
+                    }
+                }
+            }
+    return count;
+}
+
+// One thread per pixel (t = place in the render order), one XorShift stream per image index.  COMMIT = false
+// counts the pixel's hitpoints (hcnt[t]); COMMIT = true stores them from slot hoff[t] on.
+template <bool COMMIT>
+__global__ void __launch_bounds__(256) k_ppm_eye(DevScene sc, EyeParams ep, HpArrays out, unsigned long long* __restrict__ counters, int32_t* __restrict__ err)
+{
+    STAGE_SCENE(sc);
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int npix = ep.W * ep.H;
+    uint32_t rays = 0;
+    if (t < npix) {
+        const int index = (ep.H - t / ep.W - 1) * ep.W + t % ep.W;
+        XorShift rng = make_stream(ep.seed_eye, (uint64_t)index);
+        const int n = ppm_pixel<XorShift, COMMIT>(sc, ep, out, t, COMMIT ? ep.hoff[t] : 0ll, rng, rays);
+        if constexpr (COMMIT) { if ((long long)n != ep.hoff[t + 1] - ep.hoff[t]) err[5] = 1; }
+        else ep.hcnt[t] = (uint32_t)n;
+    }
+    if constexpr (COMMIT) {
+        for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off);
+        if ((threadIdx.x & 63) == 0 && rays) atomicAdd(&counters[0], (unsigned long long)rays);
+    }
+}
+
+// image assembly of render(), src/progressive_photonmapping.h:807-813: one thread per pixel sums its
+// hitpoints in creation order (the reference walks its kd-sorted vector; the two orders differ by the
+// rounding of a sum of a few terms).
+__global__ void k_ppm_resolve(HpArrays hp, DevScene sc, const long long* __restrict__ hoff, int W, int H, int64_t photon_num, double spp, double* __restrict__ image)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= W * H) return;
+    const int index = (H - t / W - 1) * W + t % W;
+    const long long P = hp.P;
+    d3 c = mk(0, 0, 0);
+    for (long long h = hoff[t]; h < hoff[t + 1]; h++) {
+        const d3 em = ld3(sc.sp[hp.obj[h]].emission);
+        const d3 flux = mk(hp.flux[h], hp.flux[P + h], hp.flux[2 * P + h]);
+        c = c + (em + flux * hp.w[h] * (1.0 / (SPPM_PI * hp.r2[h] * (double)photon_num))) / spp;
+    }
+    image[3 * (size_t)index] = c.x; image[3 * (size_t)index + 1] = c.y; image[3 * (size_t)index + 2] = c.z;
+}
+
 // ---- reference-stream mode of the eye pass ----------------------------------------------------------
 // The reference draws every pixel's samples from ONE sequential stream (src/sppm2.h:621), so pixel t
 // starts where pixels 0..t-1 stopped.  Most pixels consume a number of draws that does not depend on
@@ -212,6 +354,7 @@ __global__ void __launch_bounds__(256) k_eye_pass(DevScene sc, EyeParams ep, HpA
 // pixels in render order and resolves the dynamic ones with the real stream, then the pass itself runs
 // in parallel from the offsets found.  DYN_PIXEL marks a dynamic pixel in cnt[].
 #define DYN_PIXEL 0x80000000u
+template <int ALGO>  // 0: sppm2.h, 1: progressive_photonmapping.h
 __global__ void __launch_bounds__(256) k_eye_classify(DevScene sc, EyeParams ep, HpArrays hp)
 {
     STAGE_SCENE(sc);
@@ -220,10 +363,12 @@ __global__ void __launch_bounds__(256) k_eye_classify(DevScene sc, EyeParams ep,
     ProbeRng rng;
     rng.count = 0; rng.dyn = false;
     uint32_t rays = 0;
-    eye_pixel<ProbeRng, false>(sc, ep, hp, hp, t, rng, rays);
+    if constexpr (ALGO == 0) eye_pixel<ProbeRng, false>(sc, ep, hp, hp, t, rng, rays);
+    else (void)ppm_pixel<ProbeRng, false>(sc, ep, hp, t, 0ll, rng, rays);
     ep.cnt[t] = rng.dyn ? DYN_PIXEL : (uint32_t)rng.count;
 }
 
+template <int ALGO>
 __global__ void __launch_bounds__(64) k_eye_offsets(DevScene sc, EyeParams ep, HpArrays hp, int32_t* __restrict__ err)
 {
     STAGE_SCENE(sc);
@@ -250,7 +395,8 @@ __global__ void __launch_bounds__(64) k_eye_offsets(DevScene sc, EyeParams ep, H
                     ep.off[t] = cur;
                     StreamRng rng; rng.u = ep.u; rng.pos = (int64_t)cur; rng.end = ep.u_len;
                     uint32_t rays = 0;
-                    eye_pixel<StreamRng, false>(sc, ep, hp, hp, t, rng, rays);
+                    if constexpr (ALGO == 0) eye_pixel<StreamRng, false>(sc, ep, hp, hp, t, rng, rays);
+                    else (void)ppm_pixel<StreamRng, false>(sc, ep, hp, t, 0ll, rng, rays);
                     used = (unsigned long long)rng.pos - cur;
                     if (rng.stop()) err[4] = 1;
                 }
@@ -280,11 +426,37 @@ __global__ void __launch_bounds__(256) k_eye_pass_stream(DevScene sc, EyeParams 
     if ((threadIdx.x & 63) == 0 && rays) atomicAdd(&counters[0], (unsigned long long)rays);
 }
 
+// classic PPM on the reference's stream: pixel t reads from off[t]; COMMIT as in k_ppm_eye
+template <bool COMMIT>
+__global__ void __launch_bounds__(256) k_ppm_eye_stream(DevScene sc, EyeParams ep, HpArrays out, unsigned long long* __restrict__ counters, int32_t* __restrict__ err)
+{
+    STAGE_SCENE(sc);
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int npix = ep.W * ep.H;
+    uint32_t rays = 0;
+    if (t < npix) {
+        StreamRng rng; rng.u = ep.u; rng.pos = (int64_t)ep.off[t]; rng.end = ep.u_len;
+        const int n = ppm_pixel<StreamRng, COMMIT>(sc, ep, out, t, COMMIT ? ep.hoff[t] : 0ll, rng, rays);
+        const unsigned long long next = t + 1 < npix ? ep.off[t + 1] : ep.total[0];
+        if ((unsigned long long)rng.pos != next) err[5] = 1;
+        if constexpr (COMMIT) { if ((long long)n != ep.hoff[t + 1] - ep.hoff[t]) err[5] = 1; }
+        else ep.hcnt[t] = (uint32_t)n;
+    }
+    if constexpr (COMMIT) {
+        for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off);
+        if ((threadIdx.x & 63) == 0 && rays) atomicAdd(&counters[0], (unsigned long long)rays);
+    }
+}
+
 struct TraceParams {
     int pass; int64_t first, count, photons_per_pass; uint32_t seed_photon; double flux_scale;
     int64_t rec_cap;
     // reference-stream mode only
     const double* u; int64_t u_len; const uint32_t* start; uint32_t* consumed;
+    // classic PPM (src/progressive_photonmapping.h:326,339,344,385-387): depth starts at 0, so the first diffuse
+    // hit deposits too, and the flux that reaches a hitpoint is multiply(obj.color, current_flux) of the PHOTON's
+    // surface: the record stores that product
+    int ppm;
 };
 struct RecArrays { uint64_t* key; double* f; int64_t cap; };  // f[9][cap]
 
@@ -324,12 +496,12 @@ __device__ __forceinline__ void photon_emit(const DevScene& sc, const TraceParam
     ps.org = source_pos;
     ps.dir = cosine_sampling(w, u, v, ps.rng);
     ps.flux = ld3(sc.sp[0].emission) * 4.0 * tp.flux_scale;
-    ps.depth = -1;
+    ps.depth = tp.ppm ? 0 : -1;
 }
 
 // one iteration of the while loop of create_photon; returns false when the path ends
 template <class RNG>
-__device__ __forceinline__ bool photon_bounce(const DevScene& sc, PhotonState<RNG>& ps, Deposit& dep, int32_t* __restrict__ err, uint32_t& rays)
+__device__ __forceinline__ bool photon_bounce(const DevScene& sc, PhotonState<RNG>& ps, Deposit& dep, int32_t* __restrict__ err, uint32_t& rays, const bool ppm)
 {
     if (ps.rng.stop()) return false;
     if (max3(ps.flux) <= 0.0) return false;
@@ -348,7 +520,7 @@ __device__ __forceinline__ bool photon_bounce(const DevScene& sc, PhotonState<RN
             // the record is stored by the caller, where the whole wavefront has reconverged
             dep.want = true;
             dep.key = ((uint64_t)ps.index << 16) | ((uint64_t)ps.depth << 1) | (flip ? 1ull : 0ull);
-            dep.pos = is.position; dep.nrm = is.normal; dep.flux = ps.flux;
+            dep.pos = is.position; dep.nrm = is.normal; dep.flux = ppm ? had(color, ps.flux) : ps.flux;
         }
         const double prob = (color.x + color.y + color.z) / 3;
         if (!(prob > ps.rng.next01())) return false;
@@ -415,7 +587,7 @@ __global__ void __launch_bounds__(256) k_photon_trace(DevScene sc, TraceParams t
         Deposit dep;
         dep.want = false;
         if (active) {
-            active = photon_bounce(sc, ps, dep, err, rays);
+            active = photon_bounce(sc, ps, dep, err, rays, tp.ppm != 0);
             if constexpr (MODE == 2)
                 if (!active) tp.consumed[ps.index] = ps.rng.stop() ? STREAM_OVER : (uint32_t)(ps.rng.pos - ps.index);
             if constexpr (MODE == 1)
@@ -598,6 +770,7 @@ __global__ void k_r2max(HpArrays hp, Own own, double gather_r2, unsigned long lo
 // ---- gather: each hitpoint replays the records near it in key order ------------------------------------
 struct GatherParams {
     Grid g; double gather_r2, alpha; int rule; Own own;
+    int unit_weight;  // classic PPM: the record's flux is applied as it is (no hitpoint weight or colour)
     uint64_t* tap_key; int32_t* tap_pix; unsigned long long* tap_n; int64_t tap_cap;
 };
 
@@ -630,8 +803,8 @@ __global__ void __launch_bounds__(256) k_gather(HpArrays hp, DevScene sc, RecArr
         if (hp.valid[p] && owned(gp.own, p)) {
             const d3 hpos = mk(hp.pos[p], hp.pos[P + p], hp.pos[2 * P + p]);
             const d3 hn = mk(hp.nrm[p], hp.nrm[P + p], hp.nrm[2 * P + p]);
-            const d3 hw = mk(hp.w[p], hp.w[P + p], hp.w[2 * P + p]);
-            const d3 hcol = ld3(sc.sp[hp.obj[p]].color);
+            const d3 hw = gp.unit_weight ? mk(1, 1, 1) : mk(hp.w[p], hp.w[P + p], hp.w[2 * P + p]);
+            const d3 hcol = gp.unit_weight ? mk(1, 1, 1) : ld3(sc.sp[hp.obj[p]].color);
             double r2 = hp.r2[p];
             int n = 0; double nd = 0.0; int madd = 0;
             d3 acc;
@@ -925,7 +1098,11 @@ struct sppm_ctx {
     sppm_config cfg;
     int device;
     hipStream_t stream;
-    int P;
+    int P;     // hitpoint slots: one per pixel (sppm2.h); the length of the hitpoint list (classic PPM)
+    int npix;  // width * height
+    int algo;  // cfg.algorithm
+    // classic PPM: hitpoints per pixel / first slot per pixel, by place in the render order; made by sppm_create
+    uint32_t* d_hcnt; long long* d_hoff; std::vector<long long> h_hoff;
     int tiles_x, tiles_y, n_tiles, tile_first, tile_stride, n_owned;
     int gather_mode;          // 1 = tile gather (default), 0 = simple per-hitpoint gather (cross-check)
     int64_t table_cap;        // entries of the (slab, cell) table
@@ -993,7 +1170,7 @@ struct sppm_ctx {
     int sampler;
     std::mt19937 eye_eng;               // one engine for all eye passes, src/sppm2.h:621
     std::vector<double> eye_pending;    // drawn from eye_eng, not yet consumed by a pass
-    double *d_u_eye, *d_u_ph; int64_t u_eye_cap, u_ph_cap;
+    double *d_u_eye, *d_u_ph; int64_t u_eye_cap, u_ph_cap, u_eye_len;
     uint32_t *d_eye_cnt, *d_ph_start, *d_ph_consumed; int64_t ph_start_cap, ph_consumed_cap;
     unsigned long long *d_eye_off, *d_stream_total;
     int64_t stream_len;                 // uploaded length of the photon stream of stream_pass
@@ -1052,6 +1229,7 @@ static int64_t env_i64(const char* name, int64_t dflt)
 }
 
 static void set_cur(sppm_ctx* c, int b);
+static int ppm_prepare(sppm_ctx* c);
 
 extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres, int32_t n_spheres, void* stream, sppm_ctx** out)
 {
@@ -1065,13 +1243,17 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
     if (cfg->update_rule != 0 && cfg->update_rule != 1) return fail(SPPM_ERR_INVALID, "sppm_create: update_rule must be 0 or 1");
     if (cfg->ownership != 0 && cfg->ownership != 1) return fail(SPPM_ERR_INVALID, "sppm_create: ownership must be 0 (screen tiles) or 1 (ranges of the hitpoints' Morton order)");
     if (cfg->sampler != 0 && cfg->sampler != 1) return fail(SPPM_ERR_INVALID, "sppm_create: sampler must be 0 (XorShift streams) or 1 (reference mt19937 stream)");
+    if (cfg->algorithm != 0 && cfg->algorithm != 1) return fail(SPPM_ERR_INVALID, "sppm_create: algorithm must be 0 (sppm2.h) or 1 (progressive_photonmapping.h)");
+    if (cfg->algorithm == 1 && (cfg->update_rule != 0 || cfg->tile_stride > 1 || cfg->ownership != 0))
+        return fail(SPPM_ERR_INVALID, "sppm_create: classic progressive photon mapping runs with update_rule 0 on one GPU (tile_stride <= 1, ownership 0)");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
         return fail(SPPM_ERR_HIP, "sppm_create: no HIP device (this library has no CPU path)");
     sppm_ctx* c = new sppm_ctx();
     c->cfg = *cfg;
     c->stream = (hipStream_t)stream;
-    c->P = cfg->width * cfg->height;
+    c->P = c->npix = cfg->width * cfg->height;
+    c->algo = cfg->algorithm; c->d_hcnt = nullptr; c->d_hoff = nullptr;
     c->tiles_x = (cfg->width + 7) / 8; c->tiles_y = (cfg->height + 7) / 8; c->n_tiles = c->tiles_x * c->tiles_y;
     c->tile_stride = cfg->tile_stride > 0 ? cfg->tile_stride : 1;
     c->tile_first = cfg->tile_stride > 0 ? cfg->tile_first : 0;
@@ -1092,7 +1274,7 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
     c->eye_stream = nullptr; c->ev_eye_done = c->ev_eye_go = nullptr; c->d_order_v[0] = c->d_order_v[1] = nullptr; c->d_hp_bb_v[0] = c->d_hp_bb_v[1] = nullptr;
     c->tap_cap = 0; c->d_tap_key = nullptr; c->d_tap_pix = nullptr; c->d_tap_n = nullptr;
     c->sampler = cfg->sampler; c->eye_eng.seed(cfg->seed_eye);
-    c->d_u_eye = c->d_u_ph = nullptr; c->u_eye_cap = c->u_ph_cap = 0; c->d_eye_cnt = nullptr; c->d_ph_start = c->d_ph_consumed = nullptr;
+    c->d_u_eye = c->d_u_ph = nullptr; c->u_eye_cap = c->u_ph_cap = 0; c->u_eye_len = 0; c->d_eye_cnt = nullptr; c->d_ph_start = c->d_ph_consumed = nullptr;
     c->ph_start_cap = c->ph_consumed_cap = 0; c->d_eye_off = c->d_stream_total = nullptr; c->stream_len = 0; c->stream_pass = -1;
     c->timing = 0; c->gather_ns = c->gather_launches = c->gather_batches = 0; c->trace_ns = c->trace_launches = 0; c->photons_traced = c->records_total = 0;
     int rc = 0;
@@ -1116,6 +1298,12 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
         const double rp = h_spheres[0].radius * SPPM_PI;
         c->flux_scale = rp * rp;
     }
+    if (c->sampler == 1) {
+        TRY(dev_alloc(c, &c->d_eye_cnt, (size_t)c->npix)); TRY(dev_alloc(c, &c->d_eye_off, (size_t)c->npix));
+        TRY(dev_alloc(c, &c->d_stream_total, 1));
+    }
+    TRY(dev_alloc(c, &c->d_err, 8));
+    if (c->algo == 1) TRY(ppm_prepare(c));  // counts the hitpoint list: c->P becomes its length
     const size_t P = (size_t)c->P;
     c->hp.P = c->P;
     TRY(dev_alloc(c, &c->hp.pos, 3 * P)); TRY(dev_alloc(c, &c->hp.nrm, 3 * P)); TRY(dev_alloc(c, &c->hp.w, 3 * P));
@@ -1148,9 +1336,8 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
     c->prefetch = (int)env_i64("SPPM_PREFETCH", 1);
     if (c->sampler == 1) {
         c->prefetch = 0;  // a pass's photon stream offsets exist only once its photon pass has begun
-        TRY(dev_alloc(c, &c->d_eye_cnt, (size_t)cfg->width * cfg->height)); TRY(dev_alloc(c, &c->d_eye_off, (size_t)cfg->width * cfg->height));
-        TRY(dev_alloc(c, &c->d_stream_total, 1));
     }
+    if (c->algo == 1) c->prefetch = 0;  // one eye pass, one run of photons: nothing follows to work ahead on
     if (hipStreamCreateWithFlags(&c->trace_stream, hipStreamNonBlocking) != hipSuccess) { sppm_destroy(c); return fail(SPPM_ERR_HIP, "creating the trace stream failed"); }
     for (int b = 0; b < 2; b++)
         if (hipEventCreateWithFlags(&c->ev_traced[b], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_free[b], hipEventDisableTiming) != hipSuccess) {
@@ -1179,7 +1366,7 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
     if (hipHostMalloc((void**)&c->h_stat, 2 * sizeof(sppm_ctx::StatSlot), hipHostMallocDefault) != hipSuccess) { sppm_destroy(c); return fail(SPPM_ERR_HIP, "pinned host memory for the tile statistics"); }
     for (int b = 0; b < 2; b++)
         if (hipEventCreateWithFlags(&c->ev_stat[b], hipEventDisableTiming) != hipSuccess) { sppm_destroy(c); return fail(SPPM_ERR_HIP, "creating events failed"); }
-    TRY(dev_alloc(c, &c->d_counters, 24)); TRY(dev_alloc(c, &c->d_r2max, 1)); TRY(dev_alloc(c, &c->d_err, 8));
+    TRY(dev_alloc(c, &c->d_counters, 24)); TRY(dev_alloc(c, &c->d_r2max, 1));
     TRY(dev_alloc(c, &c->d_stats, 1));
     {   // the image indices this rank owns (8x8 screen tiles dealt round-robin), in index order
         std::vector<int32_t> own;
@@ -1267,7 +1454,7 @@ static inline NearMap near_map(const sppm_ctx* c, bool use)
 extern "C" int sppm_camera_rays(sppm_ctx* c, int32_t sx, int32_t sy, double* d_rays)
 {
     if (!c || !d_rays) return fail(SPPM_ERR_INVALID, "sppm_camera_rays: null argument");
-    hipLaunchKernelGGL(k_camera_rays, dim3(nblk(c->P, 256)), dim3(256), 0, c->stream, c->cam, c->cfg.width, c->cfg.height, sx, sy, d_rays);
+    hipLaunchKernelGGL(k_camera_rays, dim3(nblk(c->npix, 256)), dim3(256), 0, c->stream, c->cam, c->cfg.width, c->cfg.height, sx, sy, d_rays);
     HIPCHK(hipGetLastError());
     return SPPM_OK;
 }
@@ -1282,6 +1469,87 @@ extern "C" int sppm_intersect(sppm_ctx* c, const double* d_rays, int64_t n, int3
 }
 
 // Eye pass on the reference's sequential stream (see k_eye_classify / k_eye_offsets / k_eye_pass_stream).
+
+// ---- classic PPM: the hitpoint list ----------------------------------------------------------------------
+static EyeParams eye_params(const sppm_ctx* c, int32_t pass)
+{
+    EyeParams ep;
+    memset(&ep, 0, sizeof ep);
+    ep.cam = c->cam; ep.W = c->cfg.width; ep.H = c->cfg.height; ep.samples = c->cfg.samples; ep.supersamples = c->cfg.supersamples;
+    ep.pass = pass; ep.seed_eye = c->cfg.seed_eye; ep.initial_r2 = c->cfg.initial_radius2; ep.double_nee = c->cfg.double_nee;
+    ep.cnt = c->d_eye_cnt; ep.off = c->d_eye_off; ep.total = c->d_stream_total; ep.hcnt = c->d_hcnt; ep.hoff = c->d_hoff;
+    ep.u = c->d_u_eye; ep.u_len = c->u_eye_len;
+    return ep;
+}
+
+// Part of sppm_create: trace every pixel's eye paths once without storing anything, to learn how many
+// hitpoints each pixel leaves (create_point appends to a vector, src/progressive_photonmapping.h:531).  The
+// prefix sum gives each pixel its slots in creation order; sppm_eye_pass(0) then stores the hitpoints.  In
+// reference-stream mode the per-pixel stream offsets are found first (classify / walk, as for sppm2.h).
+static int ppm_prepare(sppm_ctx* c)
+{
+    hipStream_t st = c->stream;
+    const int npix = c->npix;
+    int rc;
+    if ((rc = dev_alloc(c, &c->d_hcnt, (size_t)npix))) return rc;
+    if ((rc = dev_alloc(c, &c->d_hoff, (size_t)npix + 1))) return rc;
+    HpArrays none;
+    memset(&none, 0, sizeof none);
+    EyeParams ep = eye_params(c, 0);
+    if (c->sampler == 1) {
+        std::uniform_real_distribution<double> dist(0.0, 1.0);
+        const int64_t paths = (int64_t)npix * c->cfg.samples * c->cfg.supersamples * c->cfg.supersamples;
+        int64_t need = 8 * paths + 4096;
+        hipLaunchKernelGGL(k_eye_classify<1>, dim3(nblk(npix, 256)), dim3(256), scene_lds(c), st, scene_of(c), ep, none);
+        HIPCHK(hipGetLastError());
+        for (int attempt = 0;; attempt++) {
+            while ((int64_t)c->eye_pending.size() < need) c->eye_pending.push_back(dist(c->eye_eng));
+            if ((rc = grow(c, &c->d_u_eye, &c->u_eye_cap, need))) return rc;
+            HIPCHK(hipMemcpyAsync(c->d_u_eye, c->eye_pending.data(), (size_t)need * 8, hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemsetAsync(c->d_err + 4, 0, sizeof(int32_t), st));
+            c->u_eye_len = need;
+            ep = eye_params(c, 0);
+            hipLaunchKernelGGL(k_eye_offsets<1>, dim3(1), dim3(64), scene_lds(c), st, scene_of(c), ep, none, c->d_err);
+            HIPCHK(hipGetLastError());
+            int32_t short_stream = 0;
+            HIPCHK(hipMemcpyAsync(&short_stream, c->d_err + 4, sizeof short_stream, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            if (!short_stream) break;
+            if (attempt >= 6) return fail(SPPM_ERR_OVERFLOW, "sppm_create: the eye paths consume more of the stream than 512 draws per path");
+            need *= 2;
+        }
+        hipLaunchKernelGGL(k_ppm_eye_stream<false>, dim3(nblk(npix, 256)), dim3(256), scene_lds(c), st, scene_of(c), ep, none, (unsigned long long*)nullptr, c->d_err);
+    } else
+        hipLaunchKernelGGL(k_ppm_eye<false>, dim3(nblk(npix, 256)), dim3(256), scene_lds(c), st, scene_of(c), ep, none, (unsigned long long*)nullptr, c->d_err);
+    HIPCHK(hipGetLastError());
+    std::vector<uint32_t> cnt((size_t)npix);
+    HIPCHK(hipMemcpyAsync(cnt.data(), c->d_hcnt, (size_t)npix * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    c->h_hoff.assign((size_t)npix + 1, 0);
+    for (int t = 0; t < npix; t++) c->h_hoff[(size_t)t + 1] = c->h_hoff[(size_t)t] + (long long)cnt[(size_t)t];
+    const long long nh = c->h_hoff[(size_t)npix];
+    // a work item of the tile gather names its tile in 20 bits (64 hitpoints per tile)
+    if (nh > (1ll << 26)) return fail(SPPM_ERR_INVALID, "sppm_create: more than 2^26 hitpoints (lower samples / supersamples)");
+    HIPCHK(hipMemcpyAsync(c->d_hoff, c->h_hoff.data(), ((size_t)npix + 1) * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+    c->P = (int)nh;
+    return 0;
+}
+
+// the eye pass of classic PPM: store the hitpoint list into view nv (same paths as ppm_prepare counted)
+static int ppm_eye_emit(sppm_ctx* c, int nv, hipStream_t st)
+{
+    if (c->P == 0) return 0;
+    const EyeParams ep = eye_params(c, 0);
+    HpArrays out = c->view[nv];
+    if (c->sampler == 1)
+        hipLaunchKernelGGL(k_ppm_eye_stream<true>, dim3(nblk(c->npix, 256)), dim3(256), scene_lds(c), st, scene_of(c), ep, out, c->d_counters, c->d_err);
+    else
+        hipLaunchKernelGGL(k_ppm_eye<true>, dim3(nblk(c->npix, 256)), dim3(256), scene_lds(c), st, scene_of(c), ep, out, c->d_counters, c->d_err);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 static int eye_pass_stream(sppm_ctx* c, EyeParams& ep)
 {
     hipStream_t st = c->stream;
@@ -1289,7 +1557,7 @@ static int eye_pass_stream(sppm_ctx* c, EyeParams& ep)
     const int64_t paths = (int64_t)c->P * c->cfg.samples * c->cfg.supersamples * c->cfg.supersamples;
     int64_t need = 8 * paths + 4096;
     ep.cnt = c->d_eye_cnt; ep.off = c->d_eye_off; ep.total = c->d_stream_total;
-    hipLaunchKernelGGL(k_eye_classify, dim3(nblk(c->P, 256)), dim3(256), scene_lds(c), st, scene_of(c), ep, c->hp);
+    hipLaunchKernelGGL(k_eye_classify<0>, dim3(nblk(c->P, 256)), dim3(256), scene_lds(c), st, scene_of(c), ep, c->hp);
     HIPCHK(hipGetLastError());
     unsigned long long total = 0;
     for (int attempt = 0;; attempt++) {
@@ -1299,7 +1567,7 @@ static int eye_pass_stream(sppm_ctx* c, EyeParams& ep)
         HIPCHK(hipMemcpyAsync(c->d_u_eye, c->eye_pending.data(), (size_t)need * 8, hipMemcpyHostToDevice, st));
         HIPCHK(hipMemsetAsync(c->d_err + 4, 0, sizeof(int32_t), st));
         ep.u = c->d_u_eye; ep.u_len = need;
-        hipLaunchKernelGGL(k_eye_offsets, dim3(1), dim3(64), scene_lds(c), st, scene_of(c), ep, c->hp, c->d_err);
+        hipLaunchKernelGGL(k_eye_offsets<0>, dim3(1), dim3(64), scene_lds(c), st, scene_of(c), ep, c->hp, c->d_err);
         HIPCHK(hipGetLastError());
         int32_t short_stream = 0;
         HIPCHK(hipMemcpyAsync(&short_stream, c->d_err + 4, sizeof short_stream, hipMemcpyDeviceToHost, st));
@@ -1340,7 +1608,7 @@ static int prepare_photon_stream(sppm_ctx* c, int32_t pass, int64_t count)
         TraceParams tp;
         memset(&tp, 0, sizeof tp);
         tp.pass = pass; tp.first = 0; tp.count = len; tp.photons_per_pass = c->cfg.photons_per_pass; tp.seed_photon = c->cfg.seed_photon;
-        tp.flux_scale = c->flux_scale; tp.rec_cap = 0; tp.u = c->d_u_ph; tp.u_len = len; tp.start = nullptr; tp.consumed = c->d_ph_consumed;
+        tp.flux_scale = c->flux_scale; tp.rec_cap = 0; tp.u = c->d_u_ph; tp.u_len = len; tp.start = nullptr; tp.consumed = c->d_ph_consumed; tp.ppm = c->algo;
         const int blocks = (int)std::min<int64_t>(nblk(len, 256), 256 * 4);
         hipLaunchKernelGGL(k_photon_trace<2>, dim3(blocks), dim3(256), scene_lds(c), st, scene_of(c), tp, c->rec_buf[c->cur], c->d_rec_count_buf[c->cur],
                            c->d_trace_next_buf[c->cur], c->d_counters, c->d_err);
@@ -1365,8 +1633,11 @@ static int eye_launch(sppm_ctx* c, int32_t pass, hipStream_t st)
     EyeParams ep;
     ep.cam = c->cam; ep.W = c->cfg.width; ep.H = c->cfg.height; ep.samples = c->cfg.samples; ep.supersamples = c->cfg.supersamples;
     ep.pass = pass; ep.seed_eye = c->cfg.seed_eye; ep.initial_r2 = c->cfg.initial_radius2; ep.double_nee = c->cfg.double_nee;
-    ep.u = nullptr; ep.u_len = 0; ep.cnt = nullptr; ep.off = nullptr; ep.total = nullptr;
-    if (c->sampler == 1) {
+    ep.u = nullptr; ep.u_len = 0; ep.cnt = nullptr; ep.off = nullptr; ep.total = nullptr; ep.hcnt = nullptr; ep.hoff = nullptr;
+    if (c->algo == 1) {
+        int rc = ppm_eye_emit(c, nv, st);
+        if (rc) return rc;
+    } else if (c->sampler == 1) {
         int rc = eye_pass_stream(c, ep);  // host-driven, on the context's stream
         if (rc) return rc;
     } else {
@@ -1422,7 +1693,7 @@ static void flip_view(sppm_ctx* c)
 // depend on photons.  Assumes the caller goes on with sppm_eye_pass(pass + 1); anything else drops it.
 static int eye_prefetch(sppm_ctx* c, int32_t pass)
 {
-    if (!c->prefetch || c->sampler == 1 || c->cfg.update_rule != 0 || c->pre_eye.valid) return 0;
+    if (!c->prefetch || c->sampler == 1 || c->cfg.update_rule != 0 || c->pre_eye.valid || c->algo == 1) return 0;
     // the other view was last read by the pass before this one, whose work is all on the context's stream by now
     HIPCHK(hipEventRecord(c->ev_eye_go, c->stream));
     HIPCHK(hipStreamWaitEvent(c->eye_stream, c->ev_eye_go, 0));
@@ -1436,6 +1707,7 @@ static int eye_prefetch(sppm_ctx* c, int32_t pass)
 extern "C" int sppm_eye_pass(sppm_ctx* c, int32_t pass)
 {
     if (!c || pass < 0) return fail(SPPM_ERR_INVALID, "sppm_eye_pass: bad argument");
+    if (c->algo == 1 && pass != 0) return fail(SPPM_ERR_INVALID, "sppm_eye_pass: classic progressive photon mapping traces its hitpoints once (pass 0)");
     if (c->pre_eye.valid) {
         c->pre_eye.valid = 0;
         if (c->pre_eye.pass == pass) {  // computed ahead: order it before what follows on the context's stream
@@ -1472,7 +1744,7 @@ static int trace_into(sppm_ctx* c, int b, int32_t pass, int64_t first, int64_t c
     const int trace_blocks = (int)std::min<int64_t>(nblk(count, 256), env_i64("SPPM_TRACE_BLOCKS", 256 * 4));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->timing) { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventRecord(e0, st)); }
-    tp.u = nullptr; tp.u_len = 0; tp.start = nullptr; tp.consumed = nullptr;
+    tp.u = nullptr; tp.u_len = 0; tp.start = nullptr; tp.consumed = nullptr; tp.ppm = c->algo;
     if (c->sampler == 1) {
         if (c->stream_pass != pass) return fail(SPPM_ERR_STATE, "reference-stream mode: the pass's stream offsets are made by sppm_photon_pass(pass, 0, photons)");
         tp.u = c->d_u_ph; tp.u_len = c->stream_len; tp.start = c->d_ph_start;
@@ -1645,6 +1917,7 @@ static int gather_simple(sppm_ctx* c)
 {
     hipStream_t st = c->stream;
     const uint32_t nb = c->n_buckets;
+    if (c->P == 0) return finish_batch(c);
     HIPCHK(hipMemsetAsync(c->d_r2max, 0, sizeof(unsigned long long), st));
     hipLaunchKernelGGL(k_r2max, dim3(std::min(nblk(c->P, 256), 2048)), dim3(256), 0, st, c->hp, own_of(c), c->cfg.gather_radius2, c->d_r2max);
     unsigned long long bits = 0;
@@ -1663,7 +1936,7 @@ static int gather_simple(sppm_ctx* c)
     hipLaunchKernelGGL(k_grid_scatter, dim3(2048), dim3(256), 0, st, c->rec_u, c->rec_s, c->d_rec_count, c->d_rec_bucket, c->d_cursor);
     GatherParams gp;
     gp.g = g; gp.gather_r2 = c->cfg.gather_radius2; gp.alpha = c->cfg.alpha; gp.rule = c->cfg.update_rule;
-    gp.own = own_of(c);
+    gp.own = own_of(c); gp.unit_weight = c->algo;
     gp.tap_key = c->d_tap_key; gp.tap_pix = c->d_tap_pix; gp.tap_n = c->d_tap_n; gp.tap_cap = c->tap_cap;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->timing) { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventRecord(e0, st)); }
@@ -1808,7 +2081,7 @@ static int gather_tiles(sppm_ctx* c)
     const TileGrid g = BS.g;
     TileParams tp;
     memset(&tp, 0, sizeof tp);
-    tp.gather_r2 = c->cfg.gather_radius2; tp.alpha = c->cfg.alpha; tp.rule = c->cfg.update_rule;
+    tp.gather_r2 = c->cfg.gather_radius2; tp.alpha = c->cfg.alpha; tp.rule = c->cfg.update_rule; tp.unit_weight = c->algo;
     tp.order = c->d_order; tp.n_pix = c->n_own_pix; tp.n_owned = c->n_owned;
     tp.tap_key = c->d_tap_key; tp.tap_pix = c->d_tap_pix; tp.tap_n = c->d_tap_n; tp.tap_cap = c->tap_cap;
     tp.g = g;
@@ -2007,7 +2280,7 @@ extern "C" int sppm_photon_pass(sppm_ctx* c, int32_t pass, int64_t first, int64_
 extern "C" int sppm_end_pass(sppm_ctx* c)
 {
     if (!c) return fail(SPPM_ERR_INVALID, "sppm_end_pass: null context");
-    if (c->cfg.update_rule != 1) return SPPM_OK;
+    if (c->cfg.update_rule != 1 || c->P == 0) return SPPM_OK;
     hipLaunchKernelGGL(k_end_pass, dim3(nblk(c->P, 256)), dim3(256), 0, c->stream, c->hp, own_of(c), c->cfg.alpha);
     HIPCHK(hipGetLastError());
     return SPPM_OK;
@@ -2016,7 +2289,11 @@ extern "C" int sppm_end_pass(sppm_ctx* c)
 extern "C" int sppm_resolve(sppm_ctx* c, int32_t pass, int64_t photon_num, double* d_image)
 {
     if (!c || !d_image || pass < 0 || photon_num < 1) return fail(SPPM_ERR_INVALID, "sppm_resolve: bad argument");
-    hipLaunchKernelGGL(k_resolve, dim3(nblk(c->P, 256)), dim3(256), 0, c->stream, c->hp, pass, photon_num, c->cfg.update_rule, d_image);
+    if (c->algo == 1)
+        hipLaunchKernelGGL(k_ppm_resolve, dim3(nblk(c->npix, 256)), dim3(256), 0, c->stream, c->hp, scene_of(c), c->d_hoff, c->cfg.width, c->cfg.height, photon_num,
+                           (double)(c->cfg.samples * (c->cfg.supersamples * c->cfg.supersamples)), d_image);
+    else
+        hipLaunchKernelGGL(k_resolve, dim3(nblk(c->P, 256)), dim3(256), 0, c->stream, c->hp, pass, photon_num, c->cfg.update_rule, d_image);
     HIPCHK(hipGetLastError());
     return SPPM_OK;
 }
@@ -2158,6 +2435,25 @@ extern "C" int sppm_download_hitpoints(sppm_ctx* c, int32_t* h_valid, int32_t* h
     };
     if (h_flux) { int rc = soa3(c->cfg.update_rule == 0 ? c->hp.flux : c->hp.tau, h_flux); if (rc) return rc; }
     if (h_ld) { int rc = soa3(c->hp.ld, h_ld); if (rc) return rc; }
+    return SPPM_OK;
+}
+
+extern "C" int sppm_hitpoint_count(sppm_ctx* c, int64_t* n)
+{
+    if (!c || !n) return fail(SPPM_ERR_INVALID, "sppm_hitpoint_count: null argument");
+    *n = c->P;
+    return SPPM_OK;
+}
+
+extern "C" int sppm_download_hitpoint_pixels(sppm_ctx* c, int32_t* h_pix)
+{
+    if (!c || !h_pix) return fail(SPPM_ERR_INVALID, "sppm_download_hitpoint_pixels: null argument");
+    if (c->algo != 1) return fail(SPPM_ERR_STATE, "sppm_download_hitpoint_pixels: algorithm 0 keeps one hitpoint per image index");
+    const int W = c->cfg.width, H = c->cfg.height;
+    for (int t = 0; t < c->npix; t++) {
+        const int32_t index = (H - t / W - 1) * W + t % W;
+        for (long long h = c->h_hoff[(size_t)t]; h < c->h_hoff[(size_t)t + 1]; h++) h_pix[h] = index;
+    }
     return SPPM_OK;
 }
 

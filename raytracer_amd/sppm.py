@@ -27,7 +27,7 @@ def _sphere_array(table):
 def make_config(width, height, *, samples=1, supersamples=1, camera_position=scene.CAMERA_POSITION, camera_dir=None,
                 camera_up=scene.CAMERA_UP, screen_height=scene.SCREEN_HEIGHT, screen_dist=scene.SCREEN_DIST, alpha=0.7,
                 initial_radius2=25.0, gather_radius2=25.0, gather_max=1 << 40, update_rule=0, double_nee=1,
-                seed_eye=1000, seed_photon=2000, photons_per_pass=0, tile_first=0, tile_stride=0, sampler=0, ownership=0):
+                seed_eye=1000, seed_photon=2000, photons_per_pass=0, tile_first=0, tile_stride=0, sampler=0, ownership=0, algorithm=0):
     cfg = capi.SppmConfig()
     cfg.width, cfg.height, cfg.samples, cfg.supersamples = width, height, samples, supersamples
     cfg.camera_position[:] = camera_position
@@ -41,6 +41,7 @@ def make_config(width, height, *, samples=1, supersamples=1, camera_position=sce
     cfg.photons_per_pass = photons_per_pass
     cfg.tile_first, cfg.tile_stride = tile_first, tile_stride
     cfg.sampler = sampler  # 0: XorShift streams; 1: the reference's sequential mt19937 streams
+    cfg.algorithm = algorithm  # 0: sppm2.h (stochastic); 1: progressive_photonmapping.h (classic PPM, a list of hitpoints)
     cfg.ownership = ownership  # with tile_stride > 1 -- 0: 8x8 screen tiles round-robin; 1: ranges of the hitpoints' Morton order
     return cfg
 
@@ -58,11 +59,14 @@ class SppmContext:
         self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
         torch.cuda.set_device(self.device)
         self.cfg = cfg
-        self.P = cfg.width * cfg.height
+        self.P = cfg.width * cfg.height  # image indices
         self._spheres = _sphere_array(spheres)
         self.h = C.c_void_p()
         stream = torch.cuda.current_stream(self.device).cuda_stream
         capi.check(self.L.sppm_create(C.byref(cfg), self._spheres, len(self._spheres), C.c_void_p(stream), C.byref(self.h)))
+        n = C.c_int64()
+        capi.check(self.L.sppm_hitpoint_count(self.h, C.byref(n)))
+        self.n_hitpoints = n.value  # == P for sppm2.h; the length of the hitpoint list for classic PPM
 
     def close(self):
         if getattr(self, "h", None) is not None and self.h:
@@ -149,8 +153,14 @@ class SppmContext:
         return m
 
     # ---- taps ------------------------------------------------------------------------------------
+    def hitpoint_pixels(self):
+        """classic PPM: image index of every hitpoint of the list, in creation order."""
+        out = np.zeros(self.n_hitpoints, np.int32)
+        capi.check(self.L.sppm_download_hitpoint_pixels(self.h, out.ctypes.data))
+        return out
+
     def hitpoints(self):
-        P = self.P
+        P = self.n_hitpoints
         s = dict(valid=np.zeros(P, np.int32), obj=np.zeros(P, np.int32), hp_f=np.zeros((P, 10)), r2=np.zeros(P),
                  n=np.zeros(P, np.int32), flux=np.zeros((P, 3)), ld=np.zeros((P, 3)))
         capi.check(self.L.sppm_download_hitpoints(self.h, *[s[k].ctypes.data for k in ("valid", "obj", "hp_f", "r2", "n", "flux", "ld")]))
@@ -203,6 +213,34 @@ def save_ppm_file(filename, image, width, height):
     """edupt::save_ppm_file, src/ppm.h:22."""
     img = np.ascontiguousarray(image, dtype=np.float64)
     capi.check(capi.lib().sppm_save_ppm_file(filename.encode(), img.ctypes.data, width, height))
+
+
+def progressive_render(filename, width, height, samples, supersamples, photon_num, gather_photon_radius,
+                       gahter_max_photon_num, *, initial_radius=None, alpha=0.7, spheres=scene.CORNELL_SPHERES,
+                       seed_eye=1000, seed_photon=2000, sampler=0, write_files=True):
+    """Mirror of photonmap::progressive::render (src/progressive_photonmapping.h:709-821), the classic
+    progressive photon mapping that src/main.cpp:87 runs: one eye pass that leaves a list of hitpoints, then
+    photon_num photons, then the image.  initial_radius is progressive::InitialRadius (src/main.cpp:77 sets it
+    to gather_photon_radius, the default here; like the search radius it is used as a SQUARED length).
+    The reference also writes an image every few photons (:681-704); this mirror writes the final pair only.
+    Returns the image [H*W][3] (host array)."""
+    r2 = float(gather_photon_radius)
+    cfg = make_config(width, height, samples=samples, supersamples=supersamples, alpha=alpha,
+                      initial_radius2=r2 if initial_radius is None else float(initial_radius), gather_radius2=r2,
+                      gather_max=int(gahter_max_photon_num), seed_eye=seed_eye, seed_photon=seed_photon,
+                      photons_per_pass=photon_num, sampler=sampler, algorithm=1)
+    ctx = SppmContext(cfg, spheres)
+    try:
+        ctx.eye_pass(0)
+        ctx.photon_pass(0, photon_num)
+        image = ctx.resolve(0, photon_num).cpu().numpy()
+        ctx.check()
+        if write_files:
+            save_ppm_file(filename + ".ppm", image, width, height)
+            save_hdr_file(filename + ".hdr", image, width, height)
+    finally:
+        ctx.close()
+    return image
 
 
 class StochasticPpm:
