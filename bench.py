@@ -55,6 +55,99 @@ def cpu_baseline(width, height, photons, seconds_target=12.0):
                       f"{done} photons in {t_ph:.1f} s, {upd} hitpoint updates ({upd / t_ph:.3g} updates/s)"}
 
 
+def cpu_baseline_ppm(width, height, photons, r2, seconds_target=12.0):
+    """Classic PPM on the host: the oracle's hitpoint list + kd build, then a bounded number of photons."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol
+    from raytracer_amd.scene import CORNELL_SPHERES
+    par = ol.make_params(width, height, sampler=1, math=1, photons_per_pass=photons, gather_radius2=r2, initial_radius2=r2)
+    orc = ol.PpmOracle(par, ol.make_spheres(CORNELL_SPHERES))
+    t0 = time.perf_counter()
+    nh = orc.eye_pass()
+    t_eye = time.perf_counter() - t0
+    n, done, t_ph = 2000, 0, 0.0
+    while t_ph < seconds_target and done < photons:
+        n = min(n, photons - done)
+        t0 = time.perf_counter()
+        orc.photon_pass(0, n, first=done)
+        t_ph += time.perf_counter() - t0
+        done += n
+        n *= 2
+    upd = orc.counters()["updates"]
+    orc.close()
+    return {"value": done / t_ph, "unit": "photons/s", "cores": 1, "kind": "port",
+            "sample": f"{width}x{height}: {nh} hitpoints + kd-tree build {t_eye:.1f} s (not in value), then the first "
+                      f"{done} photons in {t_ph:.1f} s, {upd} hitpoint updates ({upd / t_ph:.3g} updates/s)"}
+
+
+def main_ppm(args):
+    """--workload ppm: BASELINE config 4, classic progressive photon mapping (src/progressive_photonmapping.h) at
+    1080p on one GPU.  A step is one batch of --photons photons applied to the fixed hitpoint list; the timed
+    region is a whole render: the eye pass that stores the list, K batches, the image.  (sppm_create, outside
+    the region as for the SPPM workload, traces the eye paths once to size the list: reported as create_ms.)"""
+    import torch
+    from raytracer_amd import sppm
+    if int(os.environ.get("WORLD_SIZE", "1")) != 1 or args.gpus != 1:
+        sys.exit("--workload ppm runs on one GPU (replicas only)")
+    torch.cuda.set_device(0)
+    W, H, M, K = args.width, args.height, args.photons, args.steps
+    r2 = args.radius2
+    total = M * K
+
+    def make(n):
+        return sppm.SppmContext(sppm.make_config(W, H, supersamples=args.supersamples, photons_per_pass=n, gather_radius2=r2,
+                                                 initial_radius2=r2, algorithm=1))
+    if args.warmup > 0:
+        scratch = make(M * args.warmup)
+        scratch.eye_pass(0)
+        scratch.photon_pass(0, M * args.warmup)
+        scratch.check()
+        scratch.close()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ctx = make(total)
+    torch.cuda.synchronize()
+    create_ms = 1e3 * (time.perf_counter() - t0)
+    ctx.set_timing(True)
+    c0 = ctx.counters()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ctx.eye_pass(0)
+    for k in range(K):
+        ctx.photon_pass(0, M, first=k * M)
+    img = ctx.resolve(0, total)
+    ctx.check()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    c1 = ctx.counters()
+    g_ns = c1["gather_ns"] - c0["gather_ns"]
+    g_launch = max(1, c1["gather_launches"] - c0["gather_launches"])
+    cand, upd = c1["candidates"] - c0["candidates"], c1["updates"] - c0["updates"]
+    alg_bytes = 28.0 * cand + 32.0 * upd
+    achieved = alg_bytes / max(g_ns, 1) if g_ns else 0.0
+    out = {
+        "metric": "photons traced/sec + hitpoint updates/sec (whole node), classic PPM Cornell 1080p",
+        "value": total / dt, "unit": "photons/s", "n_gpus": 1, "steps": K, "warmup": args.warmup, "ms_per_step": 1e3 * dt / K,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"Cornell-box classic PPM {W}x{H}, supersamples {args.supersamples}, {ctx.n_hitpoints} fixed hitpoints, "
+                               f"{K} batches of {M} photons, alpha 0.7, initial r^2 = search r^2 = {r2:g} (src/main.cpp:76-77), XorShift streams",
+                   "photons": total, "width": W, "height": H, "hitpoints": ctx.n_hitpoints, "parallelism": "1 GPU"},
+        "create_ms": create_ms, "hitpoint_updates_per_s": upd / dt, "updates_per_photon": upd / total,
+        "records_per_photon": (c1["records"] - c0["records"]) / total,
+        "trace": {"kernel": "k_photon_trace", "launches": int(c1["trace_launches"] - c0["trace_launches"]),
+                  "avg_launch_ms": (c1["trace_ns"] - c0["trace_ns"]) / 1e6 / max(1, c1["trace_launches"] - c0["trace_launches"]),
+                  "note": "on its own stream, overlapped with the gather of the batch before"},
+        "roofline": {"bound": "hbm", "kernel": "k_gather_tiles", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                     "traffic": None, "launches": int(g_launch), "avg_launch_ms": g_ns / 1e6 / g_launch, "alg_bytes_per_launch": alg_bytes / g_launch,
+                     "note": "algorithmic bytes = 28 B x (record, hitpoint) pairs distance-tested + 32 B x accepted updates (SURVEY 8d); launch durations from HIP events on the kernel's stream"},
+    }
+    assert bool(torch.isfinite(img).all())
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_ppm(W, H, total, r2)
+    print(json.dumps(out), flush=True)
+    ctx.close()
+
+
 def measured_traffic(width, height, photons, steps):
     """HBM bytes per k_gather_tiles launch from the committed PMC passes (profiles/r01_pmc_traffic.json:
     FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3 --pmc runs of this script, FETCH_SIZE
@@ -79,7 +172,12 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--photons", type=int, default=1_000_000, help="photons per pass per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=("sppm", "ppm"), default="sppm", help="sppm: BASELINE config 2/3 (the metric's workload); ppm: config 4, classic PPM")
+    ap.add_argument("--supersamples", type=int, default=1, help="--workload ppm only")
+    ap.add_argument("--radius2", type=float, default=5.0, help="--workload ppm only: InitialRadius = gather radius (squared), src/main.cpp:76-77")
     args = ap.parse_args()
+    if args.workload == "ppm":
+        return main_ppm(args)
 
     if os.environ.get("SPPM_BENCH_PROGRESS"):  # diagnostics: where every rank is, every 30 s
         import faulthandler

@@ -70,6 +70,22 @@ namespace edupt
         return s;
     }
 
+    // the scene as the C ABI takes it
+    inline std::vector<sppm_sphere> c_scene()
+    {
+        std::vector<sppm_sphere> sp;
+        for (const Sphere& s : scene()) {
+            sppm_sphere o = {};
+            o.radius = s.radius;
+            o.position[0] = s.position.x; o.position[1] = s.position.y; o.position[2] = s.position.z;
+            o.emission[0] = s.emission.x; o.emission[1] = s.emission.y; o.emission[2] = s.emission.z;
+            o.color[0] = s.color.x; o.color[1] = s.color.y; o.color[2] = s.color.z;
+            o.reflection_type = (int)s.reflection_type;
+            sp.push_back(o);
+        }
+        return sp;
+    }
+
     // src/ppm.h:22 and src/hdr.h:48 (the reference puts save_hdr_file in photonmap::utility)
     inline void save_ppm_file(const std::string& filename, const Color* image, const int width, const int height)
     {
@@ -127,16 +143,7 @@ namespace photonmap
                 cfg.update_rule = update_rule; cfg.double_nee = 1;
                 cfg.seed_eye = seed_eye; cfg.seed_photon = seed_photon;
                 cfg.photons_per_pass = photon_num;
-                std::vector<sppm_sphere> sp;
-                for (const Sphere& s : scene()) {
-                    sppm_sphere o = {};
-                    o.radius = s.radius;
-                    o.position[0] = s.position.x; o.position[1] = s.position.y; o.position[2] = s.position.z;
-                    o.emission[0] = s.emission.x; o.emission[1] = s.emission.y; o.emission[2] = s.emission.z;
-                    o.color[0] = s.color.x; o.color[1] = s.color.y; o.color[2] = s.color.z;
-                    o.reflection_type = (int)s.reflection_type;
-                    sp.push_back(o);
-                }
+                const std::vector<sppm_sphere> sp = c_scene();
                 sppm_ctx* ctx = nullptr;
                 int rc = sppm_create(&cfg, sp.data(), (int)sp.size(), nullptr, &ctx);
                 if (rc) return rc;
@@ -163,7 +170,7 @@ namespace photonmap
                     save_ppm_file(filename + ".ppm", image.data(), width, height);
                     utility::save_hdr_file(filename + ".hdr", image.data(), width, height);
                 }
-                hipFree(d_image);
+                (void)hipFree(d_image);
                 sppm_destroy(ctx);
                 return rc;
             }

@@ -34,7 +34,6 @@ struct TileParams {
     TileGrid g;
     double gather_r2, alpha;
     int rule;
-    int unit_weight;       // classic PPM: hitpoint weight and colour are not part of the flux update
     const int32_t* order;  // this rank's image indices, sorted along a Morton curve of the hitpoint positions
     int n_pix, n_owned;    // entries of order[]; virtual tiles = ceil(n_pix / 64)
     double cluster_d;      // lanes farther than this (max norm) from a tile's seed lane are replayed separately
@@ -380,7 +379,9 @@ __global__ void __launch_bounds__(256) k_items_scatter(const unsigned long long*
 #else
 #define GATHER_WAVES_ATTR
 #endif
-template <bool STAMPS>
+// UNIT: classic PPM -- the record's flux is applied as it is (no hitpoint weight or colour),
+// src/progressive_photonmapping.h:385-387
+template <bool STAMPS, bool UNIT>
 __global__ void __launch_bounds__(256) GATHER_WAVES_ATTR k_gather_tiles(HpArrays hp, DevScene sc, RecArrays rec, const uint32_t* __restrict__ cell_start,
                                                       TileParams tp, const uint32_t* __restrict__ items, unsigned int* __restrict__ q,
                                                       unsigned long long* __restrict__ counters)
@@ -427,9 +428,11 @@ __global__ void __launch_bounds__(256) GATHER_WAVES_ATTR k_gather_tiles(HpArrays
     if (live) {
         hpos = mk(hp.pos[p], hp.pos[P + p], hp.pos[2 * P + p]);
         hn = mk(hp.nrm[p], hp.nrm[P + p], hp.nrm[2 * P + p]);
-        // classic PPM (tp.unit_weight): the record's flux is applied as it is, src/progressive_photonmapping.h:385-387
-        hw = tp.unit_weight ? mk(1, 1, 1) : mk(hp.w[p], hp.w[P + p], hp.w[2 * P + p]);
-        hcol = tp.unit_weight ? mk(1, 1, 1) : ld3(sc.sp[hp.obj[p]].color);
+        if constexpr (UNIT) { hw = mk(1, 1, 1); hcol = mk(1, 1, 1); }
+        else {
+            hw = mk(hp.w[p], hp.w[P + p], hp.w[2 * P + p]);
+            hcol = ld3(sc.sp[hp.obj[p]].color);
+        }
         r2 = hp.r2[p];
         if (tp.rule == 0) { n = hp.n[p]; acc = mk(hp.flux[p], hp.flux[P + p], hp.flux[2 * P + p]); }
         else { madd = hp.madd[p]; acc = mk(hp.phi[p], hp.phi[P + p], hp.phi[2 * P + p]); }

@@ -1337,7 +1337,6 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
     if (c->sampler == 1) {
         c->prefetch = 0;  // a pass's photon stream offsets exist only once its photon pass has begun
     }
-    if (c->algo == 1) c->prefetch = 0;  // one eye pass, one run of photons: nothing follows to work ahead on
     if (hipStreamCreateWithFlags(&c->trace_stream, hipStreamNonBlocking) != hipSuccess) { sppm_destroy(c); return fail(SPPM_ERR_HIP, "creating the trace stream failed"); }
     for (int b = 0; b < 2; b++)
         if (hipEventCreateWithFlags(&c->ev_traced[b], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_free[b], hipEventDisableTiming) != hipSuccess) {
@@ -2081,7 +2080,7 @@ static int gather_tiles(sppm_ctx* c)
     const TileGrid g = BS.g;
     TileParams tp;
     memset(&tp, 0, sizeof tp);
-    tp.gather_r2 = c->cfg.gather_radius2; tp.alpha = c->cfg.alpha; tp.rule = c->cfg.update_rule; tp.unit_weight = c->algo;
+    tp.gather_r2 = c->cfg.gather_radius2; tp.alpha = c->cfg.alpha; tp.rule = c->cfg.update_rule;
     tp.order = c->d_order; tp.n_pix = c->n_own_pix; tp.n_owned = c->n_owned;
     tp.tap_key = c->d_tap_key; tp.tap_pix = c->d_tap_pix; tp.tap_n = c->d_tap_n; tp.tap_cap = c->tap_cap;
     tp.g = g;
@@ -2120,9 +2119,11 @@ static int gather_tiles(sppm_ctx* c)
         tp.item_times = d_item_times;
     }
     if (getenv("SPPM_STAMPS"))
-        hipLaunchKernelGGL(k_gather_tiles<true>, dim3(gather_blocks), dim3(256), 0, st, c->hp, scene_of(c), BS.rec_s, BS.cell_start, tp, c->d_items, c->d_item_q, c->d_counters);
+        hipLaunchKernelGGL((k_gather_tiles<true, false>), dim3(gather_blocks), dim3(256), 0, st, c->hp, scene_of(c), BS.rec_s, BS.cell_start, tp, c->d_items, c->d_item_q, c->d_counters);
+    else if (c->algo == 1)
+        hipLaunchKernelGGL((k_gather_tiles<false, true>), dim3(gather_blocks), dim3(256), 0, st, c->hp, scene_of(c), BS.rec_s, BS.cell_start, tp, c->d_items, c->d_item_q, c->d_counters);
     else
-        hipLaunchKernelGGL(k_gather_tiles<false>, dim3(gather_blocks), dim3(256), 0, st, c->hp, scene_of(c), BS.rec_s, BS.cell_start, tp, c->d_items, c->d_item_q, c->d_counters);
+        hipLaunchKernelGGL((k_gather_tiles<false, false>), dim3(gather_blocks), dim3(256), 0, st, c->hp, scene_of(c), BS.rec_s, BS.cell_start, tp, c->d_items, c->d_item_q, c->d_counters);
     if (c->timing || dbg) { HIPCHK(hipEventRecord(e1, st)); }
     HIPCHK(hipGetLastError());
     float dbg_ms = 0.f;
@@ -2250,9 +2251,17 @@ extern "C" int sppm_photon_pass(sppm_ctx* c, int32_t pass, int64_t first, int64_
         // trace ahead into the other buffer
         const int nb = 1 - b;
         int64_t nn = 0; int npass = pass; int64_t nfirst = first + done + n;
+        bool next_call = false;  // the batch traced ahead belongs to the call expected after this one
         if (done + n < count) nn = std::min(batch_size(c, c->photons_applied + (uint64_t)n), count - done - n);
-        else if (c->prefetch) {
+        else if (c->prefetch && c->algo == 1) {
+            // classic PPM has one run of photons, usually fed in several calls: the first batch of the next
+            // call, assumed to ask for as many photons as this one (dropped if it does not)
+            nfirst = first + count;
+            nn = std::max<int64_t>(0, std::min({batch_size(c, c->photons_applied + (uint64_t)n), count, c->cfg.photons_per_pass - nfirst}));
+            next_call = nn > 0;
+        } else if (c->prefetch) {
             npass = pass + 1; nfirst = first; nn = std::min(batch_size(c, c->photons_applied + (uint64_t)n), count);
+            next_call = nn > 0;
             rc = eye_prefetch(c, pass + 1);
             if (rc) return rc;
         }
@@ -2271,7 +2280,7 @@ extern "C" int sppm_photon_pass(sppm_ctx* c, int32_t pass, int64_t first, int64_
         if (rc) return rc;
         HIPCHK(hipEventRecord(c->ev_free[b], c->stream));
         done += n;
-        if (nn > 0 && npass != pass) { c->pre.valid = 1; c->pre.buf = nb; c->pre.pass = npass; c->pre.first = nfirst; c->pre.count = nn; }
+        if (next_call) { c->pre.valid = 1; c->pre.buf = nb; c->pre.pass = npass; c->pre.first = nfirst; c->pre.count = nn; }
         b = nb; n = nn;
     }
     return SPPM_OK;
