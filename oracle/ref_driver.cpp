@@ -80,7 +80,7 @@ static std::vector<unsigned char> slurp(const std::string& path)
 int main(int argc, char** argv)
 {
     if (argc < 7) {
-        fprintf(stderr, "usage: %s outdir photons passes traced_photons gather_r2 gather_k [seed_eye seed_photon]\n", argv[0]);
+        fprintf(stderr, "usage: %s outdir photons passes traced_photons gather_r2 gather_k [seed_eye seed_photon aperture focus_dist seed_lens]\n", argv[0]);
         return 2;
     }
     g_out = argv[1];
@@ -91,6 +91,12 @@ int main(int argc, char** argv)
     const int gather_k = atoi(argv[6]);
     const unsigned seed_eye = argc > 7 ? (unsigned)strtoul(argv[7], 0, 10) : 1000u;
     const unsigned seed_photon = argc > 8 ? (unsigned)strtoul(argv[8], 0, 10) : 2000u;
+    // thin-lens camera (src/cameras.h:66-139): aperture > 0 sends the eye rays through DoFCamera::get_ray, the
+    // way the commented-out member of src/sppm2.h:73-79 would (aperture 4, focus 180 there); the lens draws come
+    // from an engine of their own (src/sppm2.h:70-71), seeded seed_lens here
+    const double aperture = argc > 9 ? atof(argv[9]) : 0.0;
+    const double focus_dist = argc > 10 ? atof(argv[10]) : 180.0;
+    const unsigned seed_lens = argc > 11 ? (unsigned)strtoul(argv[11], 0, 10) : 3000u;
     const int W = REF_W, H = REF_H, P = W * H;
     const int samples = 1, supersamples = 1;
 
@@ -195,6 +201,18 @@ int main(int argc, char** argv)
     Sppm::PointMap point_map;
     std::vector<Color> image(P);
 
+    std::mt19937 lens_engine(seed_lens);
+    edupt::DoFCamera dof(W, H, 30.0, 40.0, Vec(50.0, 52.0, 220.0), normalize(Vec(0.0, -0.04, -1.0)), Vec(0.0, 1.0, 0.0), supersamples,
+                         aperture > 0.0 ? aperture : 4.0, focus_dist, lens_engine);
+    if (aperture > 0.0) {  // known answers of get_ray: the first P rays of a camera with a lens engine of its own
+        std::mt19937 e2(seed_lens);
+        edupt::DoFCamera cam2(W, H, 30.0, 40.0, Vec(50.0, 52.0, 220.0), normalize(Vec(0.0, -0.04, -1.0)), Vec(0.0, 1.0, 0.0), supersamples,
+                              aperture, focus_dist, e2);
+        std::vector<double> rays;
+        for (int y = 0; y < H; y++)
+            for (int x = 0; x < W; x++) { Ray r = cam2.get_ray(x, y, 0, 0); push3(rays, r.org); push3(rays, r.dir); }
+        dump("dof_rays.bin", rays);
+    }
     g_seed_counter = seed_eye;
     ValueSampler<double> eye_sampler(0, 1);  // one stream for every eye pass (src/sppm2.h:621)
 
@@ -206,7 +224,7 @@ int main(int argc, char** argv)
                 for (int sy = 0; sy < supersamples; sy++)
                     for (int sx = 0; sx < supersamples; sx++)
                         for (int s = 0; s < samples; s++)
-                            sppm.create_point_loop(sppm.camera.get_ray(x, y, sx, sy), &eye_sampler, &point_map, image_index);
+                            sppm.create_point_loop(aperture > 0.0 ? dof.get_ray(x, y, sx, sy) : sppm.camera.get_ray(x, y, sx, sy), &eye_sampler, &point_map, image_index);
             }
         {   // B1: the constructor leaves photon_count unset; its call site passes 0 (src/sppm2.h:208)
             auto& pts = point_map.GetData();

@@ -25,7 +25,8 @@ class OrcParams(C.Structure):
                 ("gather_radius2", C.c_double), ("gather_max", C.c_int64),
                 ("sampler", C.c_int32), ("math", C.c_int32), ("rule", C.c_int32), ("double_nee", C.c_int32),
                 ("seed_eye", C.c_uint32), ("seed_photon", C.c_uint32),
-                ("photons_per_pass", C.c_int64)]
+                ("photons_per_pass", C.c_int64),
+                ("camera_model", C.c_int32), ("seed_lens", C.c_uint32), ("aperture", C.c_double), ("focus_dist", C.c_double)]
 
 
 class OrcTap(C.Structure):
@@ -97,7 +98,7 @@ def make_spheres(table):
 def make_params(width, height, *, samples=1, supersamples=1, cam_pos=(50.0, 52.0, 220.0), cam_dir=None,
                 cam_up=(0.0, 1.0, 0.0), screen_height=30.0, screen_dist=40.0, alpha=0.7, initial_radius2=25.0,
                 gather_radius2=25.0, gather_max=1 << 40, sampler=1, math=1, rule=0, double_nee=1,
-                seed_eye=1000, seed_photon=2000, photons_per_pass=0):
+                seed_eye=1000, seed_photon=2000, photons_per_pass=0, camera_model=0, aperture=4.0, focus_dist=180.0, seed_lens=3000):
     p = OrcParams()
     p.width, p.height, p.samples, p.supersamples = width, height, samples, supersamples
     if cam_dir is None:
@@ -114,6 +115,7 @@ def make_params(width, height, *, samples=1, supersamples=1, cam_pos=(50.0, 52.0
     p.sampler, p.math, p.rule, p.double_nee = sampler, math, rule, double_nee
     p.seed_eye, p.seed_photon = seed_eye, seed_photon
     p.photons_per_pass = photons_per_pass
+    p.camera_model, p.seed_lens, p.aperture, p.focus_dist = camera_model, seed_lens, aperture, focus_dist
     return p
 
 
