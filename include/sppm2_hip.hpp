@@ -121,6 +121,9 @@ namespace photonmap
             double screen_dist = 40.0;
             // additions
             unsigned seed_eye = 1000, seed_photon = 2000;
+            int camera_model = 0;        // 1 = the thin-lens DoFCamera the reference keeps commented out (src/sppm2.h:73-79)
+            double aperture = 4, focus_dist = 180;
+            unsigned seed_lens = 3000;
             int update_rule = 0;         // 1 = per-pass (N, tau) rule of src/stochastic_ppm.h:721-741
             bool write_pass_files = true;  // the reference writes name_<i>.ppm/.hdr every pass (src/sppm2.h:687-688)
             std::vector<Color> image;      // last image, row-major, y flipped as in the reference (src/sppm2.h:632)
@@ -143,6 +146,7 @@ namespace photonmap
                 cfg.update_rule = update_rule; cfg.double_nee = 1;
                 cfg.seed_eye = seed_eye; cfg.seed_photon = seed_photon;
                 cfg.photons_per_pass = photon_num;
+                cfg.camera_model = camera_model; cfg.aperture = aperture; cfg.focus_dist = focus_dist; cfg.seed_lens = seed_lens;
                 const std::vector<sppm_sphere> sp = c_scene();
                 sppm_ctx* ctx = nullptr;
                 int rc = sppm_create(&cfg, sp.data(), (int)sp.size(), nullptr, &ctx);

@@ -99,6 +99,15 @@ typedef struct sppm_config {
                                    initial_radius2 is progressive::InitialRadius (:32, set by src/main.cpp:77).
                                    update_rule 0, one GPU.  With sampler 1 the eye pass reads the reference's one
                                    sequential stream (:760) and the photons its second one (:619). */
+    int32_t camera_model;    /* 0: PinholeCamera (src/cameras.h:11-64), what src/sppm2.h:81-86 constructs -- default.
+                                1: thin lens, DoFCamera::get_ray (src/cameras.h:66-139) with PointSamplerDisk
+                                   (src/sampler/point_sampler_disk.h:28-71): the alternative member src/sppm2.h:73-79
+                                   keeps commented out (aperture 4, focus distance 180).  Algorithm 0 only. */
+    uint32_t seed_lens;      /* the lens draws come from a generator of their own (StochasticPpm::engine_,
+                                src/sppm2.h:70-71): sampler 0 keys one XorShift stream per (pass, pixel) with it,
+                                sampler 1 seeds the one sequential mt19937 with it */
+    double aperture;         /* lens diameter (lens_radius = aperture * 0.5, src/cameras.h:117) */
+    double focus_dist;       /* distance of the plane in focus along camera_dir (src/cameras.h:133) */
 } sppm_config;
 
 typedef struct sppm_ctx sppm_ctx;

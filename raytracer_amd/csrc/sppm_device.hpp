@@ -134,7 +134,11 @@ __device__ __forceinline__ bool intersect_scene(const sppm_sphere* __restrict__ 
     (sc).sp = (const sppm_sphere*)s_scene_dyn
 
 // edupt::PinholeCamera, src/cameras.h:34-64
-struct Camera { d3 pos, sx, sy, center; double w, h, ss; };
+struct Camera {
+    d3 pos, sx, sy, center; double w, h, ss;
+    // thin lens (DoFCamera, src/cameras.h:66-139): model 1
+    int model; d3 dir, ux, uy; double lens_radius, focus_dist;
+};
 __device__ __host__ inline Camera make_camera_fields(const double* pos, const double* sx, const double* sy,
                                                      const double* center, double w, double h, double ss)
 {
@@ -144,6 +148,7 @@ __device__ __host__ inline Camera make_camera_fields(const double* pos, const do
     c.sy.x = sy[0]; c.sy.y = sy[1]; c.sy.z = sy[2];
     c.center.x = center[0]; c.center.y = center[1]; c.center.z = center[2];
     c.w = w; c.h = h; c.ss = ss;
+    c.model = 0; c.dir = c.pos; c.ux = c.pos; c.uy = c.pos; c.lens_radius = 0.0; c.focus_dist = 0.0;
     return c;
 }
 __device__ __forceinline__ void camera_ray(const Camera& c, double x, double y, int sx, int sy, d3& org, d3& dir)
@@ -154,6 +159,57 @@ __device__ __forceinline__ void camera_ray(const Camera& c, double x, double y, 
     const d3 sp = c.center + c.sx * ((r1 + x) / c.w - 0.5) + c.sy * ((r2 + y) / c.h - 0.5);
     org = c.pos;
     dir = normalize(sp - c.pos);
+}
+
+// The lens draws have a generator of their own (StochasticPpm::engine_, src/sppm2.h:70-71): mode 1 = one
+// XorShift stream per (pass, image index); mode 2 = the reference's sequential stream, two draws per ray at
+// a position known in advance; mode 0 = pinhole, no draws.
+struct LensRng {
+    XorShift xs; const double* u; long long pos; int mode;
+    // std::uniform_real_distribution<double>(-1, 1): canonical * (b - a) + a
+    __device__ __forceinline__ double next_pm1()
+    {
+        double v = 0.5;
+        if (mode == 1) v = xs.next01();
+        else if (mode == 2) v = u[pos++];
+        return v * 2.0 + -1.0;
+    }
+};
+// PointSamplerDisk::sample, src/sampler/point_sampler_disk.h:28-71 (concentric map; the reference takes cosf/sinf
+// in FLOAT: here the detmath double value rounded to float)
+__device__ __forceinline__ void disk_sample(LensRng& lens, double& lx, double& ly)
+{
+    double r, theta;
+    const double sx = lens.next_pm1();
+    const double sy = lens.next_pm1();
+    if (sx == 0.0 && sy == 0.0) { lx = 0.0; ly = 0.0; return; }
+    if (sx >= -sy) {
+        if (sx > sy) { r = sx; if (sy > 0.0) theta = sy / r; else theta = 8.0 + sy / r; }
+        else { r = sy; theta = 2.0 - sx / r; }
+    } else {
+        if (sx <= sy) { r = -sx; theta = 4.0 - sy / r; }
+        else { r = -sy; theta = 6.0 + sx / r; }
+    }
+    theta *= SPPM_PI / 4.0;
+    double sn, cs;
+    dm_sincos((double)(float)theta, &sn, &cs);
+    lx = r * (double)(float)cs; ly = r * (double)(float)sn;
+}
+// DoFCamera::get_ray, src/cameras.h:123-139
+__device__ __forceinline__ void camera_ray_lens(const Camera& c, double x, double y, int sx, int sy, LensRng& lens, d3& org, d3& dir)
+{
+    const double rate = (1.0 / c.ss);
+    const double r1 = sx * rate + rate / 2.0;
+    const double r2 = sy * rate + rate / 2.0;
+    const d3 sp = c.center + c.sx * ((r1 + x) / c.w - 0.5) + c.sy * ((r2 + y) / c.h - 0.5);
+    double lx, ly;
+    disk_sample(lens, lx, ly);
+    lx = lx * 1.0 * c.lens_radius; ly = ly * 1.0 * c.lens_radius;
+    const d3 d = normalize(sp - c.pos);
+    const double ft = fabs(c.focus_dist / dot(d, c.dir));
+    const d3 focus_point = c.pos + d * ft;
+    org = sp + c.ux * lx + c.uy * ly;
+    dir = normalize(focus_point - org);
 }
 
 __device__ __forceinline__ d3 reflect_dir(d3 d, d3 n) { return d - n * 2.0 * dot(n, d); }

@@ -35,13 +35,19 @@
 
 struct DevScene { const sppm_sphere* sp; int ns; };
 
-__global__ void k_camera_rays(Camera cam, int W, int H, int sx, int sy, double* __restrict__ rays)
+__global__ void k_camera_rays(Camera cam, int W, int H, int sx, int sy, uint32_t seed_lens, const double* __restrict__ lens_u, double* __restrict__ rays)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= W * H) return;
     const int x = i % W, y = i / W;
     d3 o, d;
-    camera_ray(cam, x, y, sx, sy, o, d);
+    if (cam.model == 1) {  // lens draws: the stream of image index (H-y-1)*W+x at pass 0, or draws 2i, 2i+1 of the sequential stream
+        LensRng l;
+        l.u = lens_u; l.pos = 2ll * i; l.mode = lens_u ? 2 : 1;
+        l.xs = make_stream(seed_lens, (uint64_t)((H - y - 1) * W + x));
+        camera_ray_lens(cam, x, y, sx, sy, l, o, d);
+    } else
+        camera_ray(cam, x, y, sx, sy, o, d);
     double* r = rays + 6 * (size_t)i;
     r[0] = o.x; r[1] = o.y; r[2] = o.z; r[3] = d.x; r[4] = d.y; r[5] = d.z;
 }
@@ -75,7 +81,20 @@ struct EyeParams {
     // classic progressive photon mapping only: hitpoints per pixel (out) / first hitpoint slot per pixel (in),
     // both indexed by the pixel's place t in the render order
     uint32_t* hcnt; const long long* hoff;
+    // thin-lens camera: seed of the per-(pass, pixel) lens streams; reference-stream mode: this pass's lens draws
+    uint32_t seed_lens; const double* lens_u;
 };
+
+__device__ __forceinline__ LensRng make_lens(const EyeParams& ep, int t, int index)
+{
+    LensRng l;
+    l.u = ep.lens_u; l.pos = 0; l.mode = 0; l.xs.seed(1u);
+    if (ep.cam.model == 1) {
+        if (ep.lens_u) { l.mode = 2; l.pos = 2ll * t * (ep.samples * ep.supersamples * ep.supersamples); }
+        else { l.mode = 1; l.xs = make_stream(ep.seed_lens, (uint64_t)ep.pass * (uint64_t)(ep.W * ep.H) + (uint64_t)index); }
+    }
+    return l;
+}
 
 // One pixel of an eye pass: the sy/sx/s loops of src/sppm2.h:628-643 around create_point_loop
 // (:156-315).  t = y*W + x is the pixel's place in the reference's render order.  COMMIT = false runs
@@ -89,11 +108,13 @@ __device__ __forceinline__ void eye_pixel(const DevScene& sc, const EyeParams& e
     d3 ld = mk(hp.ld[index], hp.ld[P + index], hp.ld[2 * P + index]);
     int valid = hp.valid[index];
     bool wrote = false;  // a hitpoint was stored for this pixel in this pass
+    LensRng lens = make_lens(ep, t, index);
     for (int sy = 0; sy < ep.supersamples; sy++)
         for (int sx = 0; sx < ep.supersamples; sx++)
             for (int s = 0; s < ep.samples; s++) {
                 d3 org, dir;
-                camera_ray(ep.cam, x, y, sx, sy, org, dir);
+                if (ep.cam.model == 1) camera_ray_lens(ep.cam, x, y, sx, sy, lens, org, dir);
+                else camera_ray(ep.cam, x, y, sx, sy, org, dir);
                 int depth = -1;
                 bool direct = true;
                 d3 weight = mk(1, 1, 1);
@@ -1169,6 +1190,8 @@ struct sppm_ctx {
     // reference-stream mode (cfg.sampler == 1): the reference's own sequential mt19937 streams
     int sampler;
     std::mt19937 eye_eng;               // one engine for all eye passes, src/sppm2.h:621
+    std::mt19937 lens_eng;              // the lens draws' engine, src/sppm2.h:70-71
+    double* d_u_lens; int64_t u_lens_cap;
     std::vector<double> eye_pending;    // drawn from eye_eng, not yet consumed by a pass
     double *d_u_eye, *d_u_ph; int64_t u_eye_cap, u_ph_cap, u_eye_len;
     uint32_t *d_eye_cnt, *d_ph_start, *d_ph_consumed; int64_t ph_start_cap, ph_consumed_cap;
@@ -1246,6 +1269,9 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
     if (cfg->algorithm != 0 && cfg->algorithm != 1) return fail(SPPM_ERR_INVALID, "sppm_create: algorithm must be 0 (sppm2.h) or 1 (progressive_photonmapping.h)");
     if (cfg->algorithm == 1 && (cfg->update_rule != 0 || cfg->tile_stride > 1 || cfg->ownership != 0))
         return fail(SPPM_ERR_INVALID, "sppm_create: classic progressive photon mapping runs with update_rule 0 on one GPU (tile_stride <= 1, ownership 0)");
+    if (cfg->camera_model != 0 && cfg->camera_model != 1) return fail(SPPM_ERR_INVALID, "sppm_create: camera_model must be 0 (pinhole) or 1 (thin lens)");
+    if (cfg->camera_model == 1 && (cfg->algorithm != 0 || !(cfg->aperture >= 0.0) || !(cfg->focus_dist > 0.0)))
+        return fail(SPPM_ERR_INVALID, "sppm_create: the thin-lens camera belongs to algorithm 0 and needs aperture >= 0 and focus_dist > 0");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
         return fail(SPPM_ERR_HIP, "sppm_create: no HIP device (this library has no CPU path)");
@@ -1273,7 +1299,7 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
     c->trace_stream = nullptr; for (int b = 0; b < 2; b++) { c->ev_traced[b] = nullptr; c->ev_free[b] = nullptr; }
     c->eye_stream = nullptr; c->ev_eye_done = c->ev_eye_go = nullptr; c->d_order_v[0] = c->d_order_v[1] = nullptr; c->d_hp_bb_v[0] = c->d_hp_bb_v[1] = nullptr;
     c->tap_cap = 0; c->d_tap_key = nullptr; c->d_tap_pix = nullptr; c->d_tap_n = nullptr;
-    c->sampler = cfg->sampler; c->eye_eng.seed(cfg->seed_eye);
+    c->sampler = cfg->sampler; c->eye_eng.seed(cfg->seed_eye); c->lens_eng.seed(cfg->seed_lens); c->d_u_lens = nullptr; c->u_lens_cap = 0;
     c->d_u_eye = c->d_u_ph = nullptr; c->u_eye_cap = c->u_ph_cap = 0; c->u_eye_len = 0; c->d_eye_cnt = nullptr; c->d_ph_start = c->d_ph_consumed = nullptr;
     c->ph_start_cap = c->ph_consumed_cap = 0; c->d_eye_off = c->d_stream_total = nullptr; c->stream_len = 0; c->stream_pass = -1;
     c->timing = 0; c->gather_ns = c->gather_launches = c->gather_batches = 0; c->trace_ns = c->trace_launches = 0; c->photons_traced = c->records_total = 0;
@@ -1293,6 +1319,15 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
         for (int k = 0; k < 3; k++) sy[k] = syn[k] * cfg->screen_height;
         for (int k = 0; k < 3; k++) center[k] = cfg->camera_position[k] + cfg->camera_dir[k] * cfg->screen_dist;
         c->cam = make_camera_fields(cfg->camera_position, sx, sy, center, (double)cfg->width, (double)cfg->height, (double)cfg->supersamples);
+        if (cfg->camera_model == 1) {  // DoFCamera constructor, src/cameras.h:104-121
+            double uy[3], uyn[3];
+            host_cross(sxn, cfg->camera_dir, uy); host_normalize(uy, uyn);  // unit_y = normalize(cross(unit_x, camera_dir))
+            c->cam.model = 1;
+            c->cam.dir.x = cfg->camera_dir[0]; c->cam.dir.y = cfg->camera_dir[1]; c->cam.dir.z = cfg->camera_dir[2];
+            c->cam.ux.x = sxn[0]; c->cam.ux.y = sxn[1]; c->cam.ux.z = sxn[2];
+            c->cam.uy.x = uyn[0]; c->cam.uy.y = uyn[1]; c->cam.uy.z = uyn[2];
+            c->cam.lens_radius = cfg->aperture * 0.5; c->cam.focus_dist = cfg->focus_dist;
+        }
     }
     {   // std::pow(light.radius * M_PI, 2.0), src/sppm2.h:348
         const double rp = h_spheres[0].radius * SPPM_PI;
@@ -1432,6 +1467,7 @@ extern "C" int sppm_destroy(sppm_ctx* c)
     if (c->ev_rows) hipEventDestroy(c->ev_rows);
     for (int b = 0; b < 2; b++) if (c->ev_stat[b]) hipEventDestroy(c->ev_stat[b]);
     if (c->d_u_eye) hipFree(c->d_u_eye);
+    if (c->d_u_lens) hipFree(c->d_u_lens);
     if (c->d_u_ph) hipFree(c->d_u_ph);
     if (c->d_ph_start) hipFree(c->d_ph_start);
     if (c->d_ph_consumed) hipFree(c->d_ph_consumed);
@@ -1453,8 +1489,20 @@ static inline NearMap near_map(const sppm_ctx* c, bool use)
 extern "C" int sppm_camera_rays(sppm_ctx* c, int32_t sx, int32_t sy, double* d_rays)
 {
     if (!c || !d_rays) return fail(SPPM_ERR_INVALID, "sppm_camera_rays: null argument");
-    hipLaunchKernelGGL(k_camera_rays, dim3(nblk(c->npix, 256)), dim3(256), 0, c->stream, c->cam, c->cfg.width, c->cfg.height, sx, sy, d_rays);
+    const double* lens_u = nullptr;
+    if (c->cam.model == 1 && c->sampler == 1) {  // a fresh lens engine: draws 2i, 2i+1 belong to ray i of the render order
+        std::mt19937 eng(c->cfg.seed_lens);
+        std::uniform_real_distribution<double> dist(0.0, 1.0);
+        std::vector<double> lu((size_t)c->npix * 2);
+        for (double& v : lu) v = dist(eng);
+        int rc = grow(c, &c->d_u_lens, &c->u_lens_cap, (int64_t)lu.size());
+        if (rc) return rc;
+        HIPCHK(hipMemcpy(c->d_u_lens, lu.data(), lu.size() * 8, hipMemcpyHostToDevice));
+        lens_u = c->d_u_lens;
+    }
+    hipLaunchKernelGGL(k_camera_rays, dim3(nblk(c->npix, 256)), dim3(256), 0, c->stream, c->cam, c->cfg.width, c->cfg.height, sx, sy, c->cfg.seed_lens, lens_u, d_rays);
     HIPCHK(hipGetLastError());
+    if (lens_u) HIPCHK(hipStreamSynchronize(c->stream));  // the buffer is reused by the next eye pass
     return SPPM_OK;
 }
 
@@ -1478,6 +1526,7 @@ static EyeParams eye_params(const sppm_ctx* c, int32_t pass)
     ep.pass = pass; ep.seed_eye = c->cfg.seed_eye; ep.initial_r2 = c->cfg.initial_radius2; ep.double_nee = c->cfg.double_nee;
     ep.cnt = c->d_eye_cnt; ep.off = c->d_eye_off; ep.total = c->d_stream_total; ep.hcnt = c->d_hcnt; ep.hoff = c->d_hoff;
     ep.u = c->d_u_eye; ep.u_len = c->u_eye_len;
+    ep.seed_lens = c->cfg.seed_lens; ep.lens_u = nullptr;
     return ep;
 }
 
@@ -1556,6 +1605,15 @@ static int eye_pass_stream(sppm_ctx* c, EyeParams& ep)
     const int64_t paths = (int64_t)c->P * c->cfg.samples * c->cfg.supersamples * c->cfg.supersamples;
     int64_t need = 8 * paths + 4096;
     ep.cnt = c->d_eye_cnt; ep.off = c->d_eye_off; ep.total = c->d_stream_total;
+    if (c->cam.model == 1) {  // two lens draws per eye ray, in render order, from the lens engine (it runs on across passes)
+        std::vector<double> lu((size_t)(2 * paths));
+        for (double& v : lu) v = dist(c->lens_eng);
+        int rc = grow(c, &c->d_u_lens, &c->u_lens_cap, 2 * paths);
+        if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(c->d_u_lens, lu.data(), lu.size() * 8, hipMemcpyHostToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));
+        ep.lens_u = c->d_u_lens;
+    }
     hipLaunchKernelGGL(k_eye_classify<0>, dim3(nblk(c->P, 256)), dim3(256), scene_lds(c), st, scene_of(c), ep, c->hp);
     HIPCHK(hipGetLastError());
     unsigned long long total = 0;
@@ -1633,6 +1691,7 @@ static int eye_launch(sppm_ctx* c, int32_t pass, hipStream_t st)
     ep.cam = c->cam; ep.W = c->cfg.width; ep.H = c->cfg.height; ep.samples = c->cfg.samples; ep.supersamples = c->cfg.supersamples;
     ep.pass = pass; ep.seed_eye = c->cfg.seed_eye; ep.initial_r2 = c->cfg.initial_radius2; ep.double_nee = c->cfg.double_nee;
     ep.u = nullptr; ep.u_len = 0; ep.cnt = nullptr; ep.off = nullptr; ep.total = nullptr; ep.hcnt = nullptr; ep.hoff = nullptr;
+    ep.seed_lens = c->cfg.seed_lens; ep.lens_u = nullptr;
     if (c->algo == 1) {
         int rc = ppm_eye_emit(c, nv, st);
         if (rc) return rc;

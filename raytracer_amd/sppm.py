@@ -27,7 +27,8 @@ def _sphere_array(table):
 def make_config(width, height, *, samples=1, supersamples=1, camera_position=scene.CAMERA_POSITION, camera_dir=None,
                 camera_up=scene.CAMERA_UP, screen_height=scene.SCREEN_HEIGHT, screen_dist=scene.SCREEN_DIST, alpha=0.7,
                 initial_radius2=25.0, gather_radius2=25.0, gather_max=1 << 40, update_rule=0, double_nee=1,
-                seed_eye=1000, seed_photon=2000, photons_per_pass=0, tile_first=0, tile_stride=0, sampler=0, ownership=0, algorithm=0):
+                seed_eye=1000, seed_photon=2000, photons_per_pass=0, tile_first=0, tile_stride=0, sampler=0, ownership=0, algorithm=0,
+                camera_model=0, aperture=4.0, focus_dist=180.0, seed_lens=3000):
     cfg = capi.SppmConfig()
     cfg.width, cfg.height, cfg.samples, cfg.supersamples = width, height, samples, supersamples
     cfg.camera_position[:] = camera_position
@@ -41,6 +42,8 @@ def make_config(width, height, *, samples=1, supersamples=1, camera_position=sce
     cfg.photons_per_pass = photons_per_pass
     cfg.tile_first, cfg.tile_stride = tile_first, tile_stride
     cfg.sampler = sampler  # 0: XorShift streams; 1: the reference's sequential mt19937 streams
+    # 0: PinholeCamera; 1: thin lens (DoFCamera, src/cameras.h:66-139; src/sppm2.h:73-79 has aperture 4, focus 180)
+    cfg.camera_model, cfg.aperture, cfg.focus_dist, cfg.seed_lens = camera_model, aperture, focus_dist, seed_lens
     cfg.algorithm = algorithm  # 0: sppm2.h (stochastic); 1: progressive_photonmapping.h (classic PPM, a list of hitpoints)
     cfg.ownership = ownership  # with tile_stride > 1 -- 0: 8x8 screen tiles round-robin; 1: ranges of the hitpoints' Morton order
     return cfg
@@ -258,6 +261,7 @@ class StochasticPpm:
         self.spheres = spheres
         self.seed_eye, self.seed_photon = 1000, 2000
         self.update_rule = 0
+        self.camera_model, self.aperture, self.focus_dist, self.seed_lens = 0, 4.0, 180.0, 3000  # 1: DoFCamera (src/sppm2.h:73-79)
         self.last_image = None
 
     def render(self, filename, width, height, samples, supersamples, photon_num, gather_photon_radius,
@@ -267,7 +271,8 @@ class StochasticPpm:
         cfg = make_config(width, height, samples=samples, supersamples=supersamples, alpha=self.alpha,
                           initial_radius2=self.initial_radius_2, gather_radius2=float(gather_photon_radius),
                           gather_max=int(gahter_max_photon_num), update_rule=self.update_rule,
-                          seed_eye=self.seed_eye, seed_photon=self.seed_photon, photons_per_pass=photon_num)
+                          seed_eye=self.seed_eye, seed_photon=self.seed_photon, photons_per_pass=photon_num,
+                          camera_model=self.camera_model, aperture=self.aperture, focus_dist=self.focus_dist, seed_lens=self.seed_lens)
         ctx = SppmContext(cfg, self.spheres)
         try:
             image = None

@@ -21,9 +21,28 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, name), name
 
 
-def test_struct_layouts_match_the_header():
+def test_struct_layouts_match_the_header(tmp_path):
+    """The ctypes structures against what a C compiler makes of include/sppm_hip.h: sizes and every field's offset."""
+    import subprocess
+    fields = lambda st: [f[0] for f in st._fields_]
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "sppm_hip.h"', 'int main(void) {',
+           'printf("%zu %zu\\n", sizeof(sppm_sphere), sizeof(sppm_config));']
+    for name, st in (("sppm_sphere", capi.SppmSphere), ("sppm_config", capi.SppmConfig)):
+        for f in fields(st):
+            src.append(f'printf("{name}.{f} %zu\\n", offsetof({name}, {f}));')
+    src += ['return 0; }']
+    c = tmp_path / "layout.c"
+    c.write_text("\n".join(src))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(c), "-o", str(exe)])
+    out = subprocess.check_output([str(exe)], text=True).split("\n")
+    assert [int(x) for x in out[0].split()] == [C.sizeof(capi.SppmSphere), C.sizeof(capi.SppmConfig)]
     assert C.sizeof(capi.SppmSphere) == 88  # edupt::Sphere, src/sphere.h:15-27
-    assert C.sizeof(capi.SppmConfig) == 4 * 4 + 9 * 8 + 2 * 8 + 2 * 8 + 8 + 8 + 4 * 4 + 8 + 6 * 4
+    for line in out[1:]:
+        if line:
+            name, off = line.split()
+            st = capi.SppmSphere if name.startswith("sppm_sphere.") else capi.SppmConfig
+            assert getattr(st, name.split(".")[1]).offset == int(off), name
 
 
 def test_writers_reproduce_reference_bytes(golden, tmp_path):
