@@ -58,9 +58,13 @@ typedef struct sppm_config {
     double initial_radius2;  /* src/sppm2.h:44 */
     double gather_radius2;   /* render()'s gather_photon_radius; a SQUARED bound (src/kdtree.h:57,126) */
     int64_t gather_max;      /* render()'s gahter_max_photon_num; the kd search's K cap (src/kdtree.h:58).
-                                This build implements the uncapped set; sppm_photon_pass reports
-                                SPPM_ERR_OVERFLOW through sppm_check() if a query would exceed K
-                                (only when check_gather_max != 0). */
+                                This build implements the uncapped set, which is the reference's set
+                                as long as no photon hit has more than K candidate hitpoints (the
+                                capped search depends on the order of the reference's kd traversal,
+                                DESIGN.md 3a).  With check_gather_max != 0 every gather first counts
+                                each query's candidates exactly (brute force over all hitpoints: a
+                                validation mode, O(records x hitpoints)); sppm_check() then reports
+                                SPPM_ERR_OVERFLOW if any exceeded K, sppm_counters [14] the largest. */
     int32_t update_rule;     /* 0: per-photon shrink, src/sppm2.h:391-421 (default, the live SPPM)
                                 1: per-pass (N, tau) update, src/stochastic_ppm.h:721-741 */
     int32_t double_nee;      /* 1 reproduces the reference's first-sight double direct sample
@@ -220,7 +224,7 @@ int sppm_download_accepted(sppm_ctx* ctx, uint64_t* h_key, int32_t* h_pix, int64
  * timing is on), [7] gather kernel launches timed, [8] in-region candidates staged, [9] staging rounds,
  * [10] live tile launches, [11] nanoseconds of device time in the photon-trace kernel (HIP events on the
  * stream it runs on), [12] trace kernel launches timed, [13] rays cast by photon tracing ([0] includes
- * them), [14..15] reserved. */
+ * them), [14] the largest number of candidate hitpoints any photon hit had (check_gather_max only), [15] reserved. */
 int sppm_counters(sppm_ctx* ctx, uint64_t h_out[16]);
 int sppm_set_timing(sppm_ctx* ctx, int32_t on);
 

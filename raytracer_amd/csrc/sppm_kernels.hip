@@ -911,6 +911,59 @@ __global__ void __launch_bounds__(256) k_gather(HpArrays hp, DevScene sc, RecArr
     }
 }
 
+// ---- K cap check (cfg.check_gather_max) ------------------------------------------------------------------
+// The reference's search keeps at most K hitpoints per photon hit (src/kdtree.h:128-133).  While no query
+// holds more than K candidates the cap never acts and the uncapped set this build computes IS the
+// reference's set.  This kernel counts, for every record of the batch, the hitpoints that pass the search
+// filter of kdtree.h:123-127 (d2 < R^2 and |dot(on, dir/|dir|)| <= 0.01 R^2) -- ALL hitpoints, not only those
+// whose own radius still reaches the record -- by brute force: a block of 256 records against the hitpoint
+// positions staged through LDS.  A validation mode: exact, O(records x hitpoints).
+__global__ void __launch_bounds__(256) k_count_queries(HpArrays hp, RecArrays rec, const unsigned long long* __restrict__ rec_count, double gather_r2,
+                                                       long long K, int32_t* __restrict__ err, unsigned long long* __restrict__ qmax)
+{
+    __shared__ double s_p[3][256];
+    const long long slots = min((long long)*rec_count, (long long)rec.cap);
+    if ((long long)blockIdx.x * 256 >= slots) return;
+    const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long cap = rec.cap, P = hp.P;
+    bool have = false;
+    unsigned long long key = 0;
+    d3 q = mk(0, 0, 0), on = mk(0, 0, 0);
+    if (r < slots) {
+        key = rec.key[r];
+        have = key != REC_INVALID;
+        if (have) {
+            q = mk(rec.f[r], rec.f[cap + r], rec.f[2 * cap + r]);
+            const d3 gn = mk(rec.f[3 * cap + r], rec.f[4 * cap + r], rec.f[5 * cap + r]);
+            on = (key & 1ull) ? gn * -1.0 : gn;
+        }
+    }
+    const double thr = gather_r2 * 0.01;
+    long long cnt = 0;
+    for (long long base = 0; base < P; base += 256) {
+        const long long h = base + threadIdx.x;
+        const bool live = h < P && hp.valid[h] != 0;
+        // a hitpoint that does not exist sits infinitely far away
+        s_p[0][threadIdx.x] = live ? hp.pos[h] : 1e300; s_p[1][threadIdx.x] = live ? hp.pos[P + h] : 1e300; s_p[2][threadIdx.x] = live ? hp.pos[2 * P + h] : 1e300;
+        __syncthreads();
+        if (have) {
+            for (int j = 0; j < 256; j++) {
+                const d3 dir = mk(s_p[0][j], s_p[1][j], s_p[2][j]) - q;
+                const double d2 = len2(dir);
+                if (d2 < gather_r2) {
+                    const double dt = dot(on, dir / sqrt(d2));  // NaN at d2 == 0: rejected, as in the reference
+                    if (fabs(dt) <= thr) cnt++;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (have) {
+        if (cnt > K) err[2] = 1;
+        atomicMax(qmax, (unsigned long long)cnt);
+    }
+}
+
 // end-of-pass update of rule 1, src/stochastic_ppm.h:721-741
 __global__ void k_end_pass(HpArrays hp, Own own, double alpha)
 {
@@ -1158,6 +1211,7 @@ struct sppm_ctx {
     unsigned long long* d_rec_count;
     unsigned long long* d_counters;  // 8: [0] rays [3] candidates [4] updates [5] selected [6] rounds [7] live tile launches
     unsigned long long* d_r2max;
+    unsigned long long* d_qmax;   // check_gather_max: the largest number of candidates any query held
     unsigned long long* d_trace_next;
     // double-buffered record buffers: the tracer fills one on its own stream while the gather consumes
     // the other.  rec_u / d_rec_count / d_trace_next above always alias buffer `cur`.
@@ -1400,7 +1454,7 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
     if (hipHostMalloc((void**)&c->h_stat, 2 * sizeof(sppm_ctx::StatSlot), hipHostMallocDefault) != hipSuccess) { sppm_destroy(c); return fail(SPPM_ERR_HIP, "pinned host memory for the tile statistics"); }
     for (int b = 0; b < 2; b++)
         if (hipEventCreateWithFlags(&c->ev_stat[b], hipEventDisableTiming) != hipSuccess) { sppm_destroy(c); return fail(SPPM_ERR_HIP, "creating events failed"); }
-    TRY(dev_alloc(c, &c->d_counters, 24)); TRY(dev_alloc(c, &c->d_r2max, 1));
+    TRY(dev_alloc(c, &c->d_counters, 24)); TRY(dev_alloc(c, &c->d_r2max, 1)); TRY(dev_alloc(c, &c->d_qmax, 1));
     TRY(dev_alloc(c, &c->d_stats, 1));
     {   // the image indices this rank owns (8x8 screen tiles dealt round-robin), in index order
         std::vector<int32_t> own;
@@ -2242,6 +2296,11 @@ static int gather_tiles(sppm_ctx* c)
 extern "C" int sppm_gather(sppm_ctx* c)
 {
     if (!c) return fail(SPPM_ERR_INVALID, "sppm_gather: null context");
+    if (c->cfg.check_gather_max && c->P > 0 && c->rec_end != c->rec_first) {
+        hipLaunchKernelGGL(k_count_queries, dim3(nblk(c->rec_u.cap, 256)), dim3(256), 0, c->stream, c->hp, c->rec_u, c->d_rec_count, c->cfg.gather_radius2,
+                           (long long)c->cfg.gather_max, c->d_err, c->d_qmax);
+        HIPCHK(hipGetLastError());
+    }
     return c->gather_mode ? gather_tiles(c) : gather_simple(c);
 }
 
@@ -2456,7 +2515,7 @@ extern "C" int sppm_check(sppm_ctx* c)
     if (rc) return rc;
     if (err[0]) return fail(SPPM_ERR_OVERFLOW, "record buffer overflow: raise SPPM_RECORD_CAP or lower SPPM_BATCH_PHOTONS");
     if (err[1]) return fail(SPPM_ERR_OVERFLOW, "a photon path exceeded 32767 bounces");
-    if (err[2]) return fail(SPPM_ERR_OVERFLOW, "a query exceeded gather_max (the K cap is not implemented)");
+    if (err[2]) return fail(SPPM_ERR_OVERFLOW, "a photon hit had more than gather_max candidate hitpoints: the reference's K cap would have acted, which this build does not reproduce (sppm_counters [14] has the largest count)");
     if (err[3]) return fail(SPPM_ERR_STATE, "a record's photon index lies outside the range declared for the batch");
     if (err[4]) return fail(SPPM_ERR_OVERFLOW, "reference-stream mode: a path ran past the uploaded part of the stream");
     if (err[5]) return fail(SPPM_ERR_STATE, "reference-stream mode: a pixel consumed a different number of draws than the offset walk found");
@@ -2605,16 +2664,17 @@ extern "C" int sppm_download_accepted(sppm_ctx* c, uint64_t* h_key, int32_t* h_p
 extern "C" int sppm_counters(sppm_ctx* c, uint64_t h_out[16])
 {
     if (!c || !h_out) return fail(SPPM_ERR_INVALID, "sppm_counters: null argument");
-    unsigned long long d[8];
+    unsigned long long d[8], qmax = 0;
     HIPCHK(hipStreamSynchronize(c->trace_stream));
     HIPCHK(hipMemcpyAsync(d, c->d_counters, sizeof d, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(&qmax, c->d_qmax, sizeof qmax, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     int rc = resolve_events(c);
     if (rc) return rc;
     h_out[0] = d[0] + d[1]; h_out[1] = c->photons_traced; h_out[2] = c->records_total + d[2]; h_out[3] = d[3]; h_out[4] = d[4];
     h_out[5] = c->gather_batches; h_out[6] = c->gather_ns; h_out[7] = c->gather_launches;
     h_out[8] = d[5]; h_out[9] = d[6]; h_out[10] = d[7]; h_out[11] = c->trace_ns; h_out[12] = c->trace_launches; h_out[13] = d[1];
-    h_out[14] = h_out[15] = 0;
+    h_out[14] = qmax; h_out[15] = 0;
     return SPPM_OK;
 }
 

@@ -28,7 +28,7 @@ def make_config(width, height, *, samples=1, supersamples=1, camera_position=sce
                 camera_up=scene.CAMERA_UP, screen_height=scene.SCREEN_HEIGHT, screen_dist=scene.SCREEN_DIST, alpha=0.7,
                 initial_radius2=25.0, gather_radius2=25.0, gather_max=1 << 40, update_rule=0, double_nee=1,
                 seed_eye=1000, seed_photon=2000, photons_per_pass=0, tile_first=0, tile_stride=0, sampler=0, ownership=0, algorithm=0,
-                camera_model=0, aperture=4.0, focus_dist=180.0, seed_lens=3000):
+                camera_model=0, aperture=4.0, focus_dist=180.0, seed_lens=3000, check_gather_max=0):
     cfg = capi.SppmConfig()
     cfg.width, cfg.height, cfg.samples, cfg.supersamples = width, height, samples, supersamples
     cfg.camera_position[:] = camera_position
@@ -44,6 +44,7 @@ def make_config(width, height, *, samples=1, supersamples=1, camera_position=sce
     cfg.sampler = sampler  # 0: XorShift streams; 1: the reference's sequential mt19937 streams
     # 0: PinholeCamera; 1: thin lens (DoFCamera, src/cameras.h:66-139; src/sppm2.h:73-79 has aperture 4, focus 180)
     cfg.camera_model, cfg.aperture, cfg.focus_dist, cfg.seed_lens = camera_model, aperture, focus_dist, seed_lens
+    cfg.check_gather_max = check_gather_max  # count every query's candidates exactly and report if any exceeds gather_max (slow)
     cfg.algorithm = algorithm  # 0: sppm2.h (stochastic); 1: progressive_photonmapping.h (classic PPM, a list of hitpoints)
     cfg.ownership = ownership  # with tile_stride > 1 -- 0: 8x8 screen tiles round-robin; 1: ranges of the hitpoints' Morton order
     return cfg
@@ -199,7 +200,7 @@ class SppmContext:
         out = np.zeros(16, np.uint64)
         capi.check(self.L.sppm_counters(self.h, out.ctypes.data))
         names = ("rays", "photons", "records", "candidates", "updates", "gather_batches", "gather_ns", "gather_launches",
-                 "selected", "rounds", "tile_launches", "trace_ns", "trace_launches", "photon_rays")
+                 "selected", "rounds", "tile_launches", "trace_ns", "trace_launches", "photon_rays", "max_query_candidates")
         return {k: int(v) for k, v in zip(names, out)}
 
     def set_timing(self, on=True):

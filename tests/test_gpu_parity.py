@@ -321,3 +321,40 @@ def test_full_size_invariants(wh):
     for k in ("n", "r2", "flux", "ld"):
         _same(outs[1][0][k], s[k], f"run-to-run {k}")
     _same(outs[1][1], img, "run-to-run image")
+
+
+def test_k_cap_check_counts_every_querys_candidates():
+    """check_gather_max: the largest number of hitpoints that pass the search filter of src/kdtree.h:123-127 for any
+    photon hit, against a brute-force count in numpy; sppm_check reports when the reference's K cap would have acted."""
+    from raytracer_amd import capi
+    W, H, M = 64, 48, 4000
+    par = ol.make_params(W, H, sampler=1, math=1, photons_per_pass=M)
+    orc = ol.Oracle(par, ol.make_spheres(CORNELL_SPHERES))
+    orc.eye_pass(0)
+    tap = orc.photon_pass(0, M, tap=True)
+    o = orc.state()
+    hp = o["hp_f"][o["valid"] > 0, 1:4]
+    q, on = tap["rec_f"][:, 0:3], tap["rec_f"][:, 6:9]
+    best = 0
+    for a in range(0, len(q), 512):
+        d = hp[None, :, :] - q[a:a + 512, None, :]
+        d2 = (d * d).sum(-1)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            dt = np.abs((on[a:a + 512, None, :] * (d / np.sqrt(d2)[..., None])).sum(-1))
+        best = max(best, int(((d2 < 25.0) & (dt <= 0.25)).sum(1).max()))
+    assert best > 4
+    for k, ok in ((best, True), (best - 1, False)):
+        ctx = sppm.SppmContext(sppm.make_config(W, H, photons_per_pass=M, gather_max=k, check_gather_max=1))
+        ctx.eye_pass(0)
+        ctx.photon_pass(0, M)
+        if ok:
+            ctx.check()
+            assert ctx.counters()["max_query_candidates"] == best
+            s = ctx.hitpoints()
+            orc_s = orc.state()
+            for name in ("n", "r2", "flux"):
+                _same(s[name], orc_s[name], f"state {name}")
+        else:
+            with pytest.raises(capi.SppmError, match="gather_max"):
+                ctx.check()
+        ctx.close()
