@@ -124,14 +124,110 @@ __device__ __forceinline__ bool intersect_scene(const sppm_sphere* __restrict__ 
     return true;
 }
 
-// Copies the sphere table (88-byte rows = 11 doubles) into dynamic LDS and points `sc` at the copy.
-// Every thread of the block must reach it; launch with sc.ns * sizeof(sppm_sphere) bytes of dynamic LDS.
-#define SPPM_MAX_SPHERES 512
+// ---- scenes too large for the brute-force loop: a uniform grid over the small spheres ---------------------
+// The reference's closest hit is a minimum over ALL spheres (src/scene.h:53-76); which spheres are tested
+// does not change it as long as every sphere the ray can hit is among them, and ties keep the reference's
+// rule (the lowest index wins: strict `<` in index order).  Spheres too large for the cells ("big": walls,
+// light) are tested for every ray; the others are listed in every cell their bounding box, grown by a
+// margin far above the rounding of the cell walk, overlaps.  The walk (Amanatides & Woo) stops when the
+// closest hit so far lies before the exit of the current cell.  The per-sphere arithmetic is the brute-force
+// loop's, so the hit is bit-identical to it.
+struct DevScene {
+    const sppm_sphere* sp; int ns;
+    // grid mode (n_cells > 0): the table stays in HBM/L2
+    int n_cells, n_big, gx, gy, gz;
+    double g_lo[3], g_inv, g_cell;
+    const int32_t* big;         // ids of the big spheres, ascending
+    const uint32_t* cell_start; // [n_cells + 1]
+    const int32_t* cell_items;  // sphere ids per cell, ascending
+};
+
+__device__ __forceinline__ void sphere_test(const sppm_sphere* __restrict__ sp, int i, d3 org, d3 dir, double& best, int& id)
+{
+    const d3 p_o = ld3(sp[i].position) - org;
+    const double b = dot(p_o, dir);
+    const double D4 = b * b - dot(p_o, p_o) + sp[i].radius * sp[i].radius;
+    const double sq = sqrt(D4);
+    const double t1 = b - sq, t2 = b + sq;
+    const bool counts = !(D4 < 0.0) && !(t1 < SPPM_EPS && t2 < SPPM_EPS);
+    const double t = (t1 > SPPM_EPS) ? t1 : t2;
+    if (counts && (t < best || (t == best && i < id))) { best = t; id = i; }
+}
+
+__device__ __forceinline__ bool intersect_scene_grid(const DevScene& sc, d3 org, d3 dir, Hit& h)
+{
+    double best = SPPM_INF;
+    int id = -1;
+    for (int k = 0; k < sc.n_big; k++) sphere_test(sc.sp, sc.big[k], org, dir, best, id);
+    // clip the ray against the grid box
+    const double o[3] = {org.x, org.y, org.z}, d[3] = {dir.x, dir.y, dir.z};
+    const int dims[3] = {sc.gx, sc.gy, sc.gz};
+    double t0 = 0.0, t1 = best;
+    bool miss = false;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const double lo = sc.g_lo[a], hi = sc.g_lo[a] + dims[a] * sc.g_cell;
+        if (d[a] == 0.0) { if (o[a] < lo || o[a] > hi) miss = true; }
+        else {
+            const double inv = 1.0 / d[a];
+            double ta = (lo - o[a]) * inv, tb = (hi - o[a]) * inv;
+            if (ta > tb) { const double tt = ta; ta = tb; tb = tt; }
+            t0 = fmax(t0, ta); t1 = fmin(t1, tb);
+        }
+    }
+    if (!miss && t0 <= t1) {
+        const double ts = t0 + 1e-9;  // just inside
+        int cx, cy, cz, sx, sy, sz;
+        double nx, ny, nz, dx, dy, dz;
+#define SPPM_DDA_AXIS(A, ci, st, tn, td)                                                                              \
+        {                                                                                                             \
+            int k_ = (int)floor((o[A] + d[A] * ts - sc.g_lo[A]) * sc.g_inv);                                          \
+            k_ = k_ < 0 ? 0 : (k_ >= dims[A] ? dims[A] - 1 : k_);                                                     \
+            ci = k_;                                                                                                  \
+            if (d[A] > 0.0) { st = 1; td = sc.g_cell / d[A]; tn = (sc.g_lo[A] + (k_ + 1) * sc.g_cell - o[A]) / d[A]; } \
+            else if (d[A] < 0.0) { st = -1; td = -sc.g_cell / d[A]; tn = (sc.g_lo[A] + k_ * sc.g_cell - o[A]) / d[A]; } \
+            else { st = 0; td = SPPM_INF; tn = SPPM_INF; }                                                            \
+        }
+        SPPM_DDA_AXIS(0, cx, sx, nx, dx)
+        SPPM_DDA_AXIS(1, cy, sy, ny, dy)
+        SPPM_DDA_AXIS(2, cz, sz, nz, dz)
+#undef SPPM_DDA_AXIS
+        for (;;) {
+            const uint32_t cell = (uint32_t)((cz * sc.gy + cy) * sc.gx + cx);
+            const uint32_t e = sc.cell_start[cell + 1];
+            for (uint32_t k = sc.cell_start[cell]; k < e; k++) sphere_test(sc.sp, sc.cell_items[k], org, dir, best, id);
+            // step into the next cell along the ray; stop once the closest hit lies inside what has been walked
+            if (nx <= ny && nx <= nz) { if (best < nx) break; cx += sx; if (cx < 0 || cx >= sc.gx) break; nx += dx; }
+            else if (ny <= nz) { if (best < ny) break; cy += sy; if (cy < 0 || cy >= sc.gy) break; ny += dy; }
+            else { if (best < nz) break; cz += sz; if (cz < 0 || cz >= sc.gz) break; nz += dz; }
+        }
+    }
+    h.distance = best;
+    h.object_id = id;
+    if (id < 0) return false;
+    h.position = org + dir * best;
+    h.normal = normalize(h.position - ld3(sc.sp[id].position));
+    return true;
+}
+
+__device__ __forceinline__ bool intersect_scene(const DevScene& sc, d3 org, d3 dir, Hit& h)
+{
+    if (sc.n_cells > 0) return intersect_scene_grid(sc, org, dir, h);
+    return intersect_scene(sc.sp, sc.ns, org, dir, h);
+}
+
+// Copies the sphere table (88-byte rows = 11 doubles) into dynamic LDS and points `sc` at the copy (small
+// scenes; a gridded scene stays where it is).  Every thread of the block must reach it; launch with
+// scene_lds() bytes of dynamic LDS.
+#define SPPM_MAX_SPHERES 512          // brute force from LDS up to here, the grid above it
+#define SPPM_MAX_SPHERES_GRID (1 << 20)
 #define STAGE_SCENE(sc)                                                                                              \
     extern __shared__ __align__(16) double s_scene_dyn[];                                                             \
-    for (int i_ = threadIdx.x; i_ < (sc).ns * 11; i_ += blockDim.x) s_scene_dyn[i_] = ((const double*)(sc).sp)[i_];   \
-    __syncthreads();                                                                                                  \
-    (sc).sp = (const sppm_sphere*)s_scene_dyn
+    if ((sc).n_cells == 0) {                                                                                          \
+        for (int i_ = threadIdx.x; i_ < (sc).ns * 11; i_ += blockDim.x) s_scene_dyn[i_] = ((const double*)(sc).sp)[i_]; \
+        __syncthreads();                                                                                              \
+        (sc).sp = (const sppm_sphere*)s_scene_dyn;                                                                    \
+    }
 
 // edupt::PinholeCamera, src/cameras.h:34-64
 struct Camera {
@@ -235,10 +331,11 @@ __device__ __forceinline__ d3 cosine_sampling(d3 w, d3 u, d3 v, RNG& rng)
 
 // next_event_est, src/radiance.h:29-70
 template <class RNG>
-__device__ __forceinline__ d3 next_event_est(const sppm_sphere* __restrict__ sp, int ns, const Hit& is, d3 on,
+__device__ __forceinline__ d3 next_event_est(const DevScene& sc, const Hit& is, d3 on,
                                              RNG& rng, uint32_t& rays)
 {
     if (is.object_id == 0) return mk(0, 0, 0);
+    const sppm_sphere* sp = sc.sp;
     const double r1 = 2 * SPPM_PI * rng.next01();
     const double r2 = 1.0 - 2.0 * rng.next01();
     const double r3 = sqrt(1.0 - r2 * r2);
@@ -255,7 +352,7 @@ __device__ __forceinline__ d3 next_event_est(const sppm_sphere* __restrict__ sp,
     const double radius2 = sp[0].radius * sp[0].radius;
     Hit sh;
     rays++;
-    const bool hit = intersect_scene(sp, ns, is.position, ldir, sh);
+    const bool hit = intersect_scene(sc, is.position, ldir, sh);
     if (hit && sh.object_id == 0 && dot1 < 0 && dot0 > 0) {
         const double G = (fabs(dot0) * fabs(dot1)) / dist2;
         const double pdf = 1.0 / (4.0 * SPPM_PI * radius2);

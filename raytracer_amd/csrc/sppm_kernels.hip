@@ -33,7 +33,6 @@
 
 // ================================ kernels ==========================================================
 
-struct DevScene { const sppm_sphere* sp; int ns; };
 
 __global__ void k_camera_rays(Camera cam, int W, int H, int sx, int sy, uint32_t seed_lens, const double* __restrict__ lens_u, double* __restrict__ rays)
 {
@@ -59,7 +58,7 @@ __global__ void k_intersect(DevScene sc, const double* __restrict__ rays, int64_
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Hit h;
-    const bool hit = intersect_scene(sc.sp, sc.ns, ld3(rays + 6 * i), ld3(rays + 6 * i + 3), h);
+    const bool hit = intersect_scene(sc, ld3(rays + 6 * i), ld3(rays + 6 * i + 3), h);
     id[i] = hit ? h.object_id : -1;
     double* o = out + 7 * i;
     o[0] = h.distance;
@@ -122,7 +121,7 @@ __device__ __forceinline__ void eye_pixel(const DevScene& sc, const EyeParams& e
                     depth++;
                     Hit is;
                     rays++;
-                    if (!intersect_scene(sc.sp, sc.ns, org, dir, is)) break;
+                    if (!intersect_scene(sc, org, dir, is)) break;
                     const sppm_sphere* obj = &sc.sp[is.object_id];
                     const d3 color = ld3(obj->color);
                     const int type = obj->reflection_type;
@@ -130,7 +129,7 @@ __device__ __forceinline__ void eye_pixel(const DevScene& sc, const EyeParams& e
                     if (direct) ld = ld + had(weight, ld3(obj->emission));
                     direct = type != SPPM_DIFFUSE;
                     if (type == SPPM_DIFFUSE) {
-                        const d3 est = next_event_est(sc.sp, sc.ns, is, on, rng, rays);
+                        const d3 est = next_event_est(sc, is, on, rng, rays);
                         ld = ld + had(weight, est);
                         // create or overwrite the pixel's hitpoint (src/sppm2.h:204-227)
                         if constexpr (COMMIT) {
@@ -256,7 +255,7 @@ __device__ __forceinline__ int ppm_pixel(const DevScene& sc, const EyeParams& ep
                     bool ended = true;
                     Hit is;
                     rays++;
-                    if (intersect_scene(sc.sp, sc.ns, org, dir, is)) {
+                    if (intersect_scene(sc, org, dir, is)) {
                         const sppm_sphere* obj = &sc.sp[is.object_id];
                         const d3 color = ld3(obj->color);
                         const int type = obj->reflection_type;
@@ -528,7 +527,7 @@ __device__ __forceinline__ bool photon_bounce(const DevScene& sc, PhotonState<RN
     if (max3(ps.flux) <= 0.0) return false;
     Hit is;
     rays++;
-    if (!intersect_scene(sc.sp, sc.ns, ps.org, ps.dir, is)) return false;
+    if (!intersect_scene(sc, ps.org, ps.dir, is)) return false;
     const sppm_sphere* obj = &sc.sp[is.object_id];
     const d3 color = ld3(obj->color);
     const int type = obj->reflection_type;
@@ -1195,6 +1194,7 @@ struct sppm_ctx {
     double split_factor, est_per_photon; int64_t est_range;
     int order_valid;
     sppm_sphere* d_spheres; int ns;
+    DevScene dscene;   // what the kernels get: the table, and for large scenes the grid over the small spheres
     Camera cam;
     double flux_scale;
     std::vector<void*> allocs;
@@ -1305,13 +1305,95 @@ static int64_t env_i64(const char* name, int64_t dflt)
     return (s && *s) ? atoll(s) : dflt;
 }
 
+
+// The grid of intersect_scene_grid (sppm_device.hpp) over a scene of many spheres, built once on the host.
+// Big spheres (radius > 16 x the lower-quartile radius: walls, lights) are tested for every ray; every other
+// sphere is listed in each cell its bounding box, grown by a margin far above the rounding of the cell walk,
+// overlaps.  Cubic cells sized for about one small sphere per two cells.
+static int build_scene_grid(sppm_ctx* c, const sppm_sphere* sp, int n)
+{
+    std::vector<double> radii((size_t)n);
+    for (int i = 0; i < n; i++) radii[(size_t)i] = sp[i].radius;
+    std::vector<double> sorted = radii;
+    std::sort(sorted.begin(), sorted.end());
+    const double r_q1 = sorted[(size_t)n / 4];
+    std::vector<int32_t> big, small;
+    for (int i = 0; i < n; i++) (radii[(size_t)i] > 16.0 * r_q1 ? big : small).push_back(i);
+    if (small.empty()) { small.swap(big); }
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (int32_t i : small)
+        for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], sp[i].position[a] - sp[i].radius); hi[a] = std::max(hi[a], sp[i].position[a] + sp[i].radius); }
+    const double diag = std::sqrt((hi[0] - lo[0]) * (hi[0] - lo[0]) + (hi[1] - lo[1]) * (hi[1] - lo[1]) + (hi[2] - lo[2]) * (hi[2] - lo[2]));
+    const double margin = 1e-7 * diag + 1e-9;
+    for (int a = 0; a < 3; a++) { lo[a] -= 2.0 * margin; hi[a] += 2.0 * margin; }
+    const double vol = std::max(1e-30, (hi[0] - lo[0]) * (hi[1] - lo[1]) * (hi[2] - lo[2]));
+    double cell = std::max(std::cbrt(vol / (2.0 * (double)small.size())), 2.0 * sorted[small.size() / 2 < (size_t)n ? small.size() / 2 : 0]);
+    if (!(cell > 0.0)) cell = std::max(diag, 1.0);
+    std::vector<uint32_t> start;
+    std::vector<int32_t> items;
+    int dims[3];
+    for (;;) {
+        int64_t ncells = 1;
+        for (int a = 0; a < 3; a++) { dims[a] = (int)std::max<int64_t>(1, std::min<int64_t>(512, (int64_t)std::ceil((hi[a] - lo[a]) / cell))); ncells *= dims[a]; }
+        bool too_fine = ncells > (1ll << 24);
+        for (int a = 0; a < 3; a++) if (dims[a] * cell < (hi[a] - lo[a])) too_fine = true;  // clamped to 512: the box must stay covered
+        if (!too_fine) {
+            const double inv = 1.0 / cell;
+            auto range = [&](int32_t i, int a, int& c0, int& c1) {
+                c0 = (int)std::floor((sp[i].position[a] - sp[i].radius - margin - lo[a]) * inv);
+                c1 = (int)std::floor((sp[i].position[a] + sp[i].radius + margin - lo[a]) * inv);
+                c0 = std::max(0, std::min(dims[a] - 1, c0)); c1 = std::max(0, std::min(dims[a] - 1, c1));
+            };
+            std::vector<uint32_t> cnt((size_t)ncells + 1, 0);
+            int64_t total = 0;
+            for (int32_t i : small) {
+                int x0, x1, y0, y1, z0, z1;
+                range(i, 0, x0, x1); range(i, 1, y0, y1); range(i, 2, z0, z1);
+                total += (int64_t)(x1 - x0 + 1) * (y1 - y0 + 1) * (z1 - z0 + 1);
+            }
+            if (total <= 64 * (int64_t)small.size() + (1 << 20)) {
+                for (int32_t i : small) {
+                    int x0, x1, y0, y1, z0, z1;
+                    range(i, 0, x0, x1); range(i, 1, y0, y1); range(i, 2, z0, z1);
+                    for (int z = z0; z <= z1; z++) for (int y = y0; y <= y1; y++) for (int x = x0; x <= x1; x++) cnt[(size_t)((z * dims[1] + y) * dims[0] + x) + 1]++;
+                }
+                for (size_t k = 1; k < cnt.size(); k++) cnt[k] += cnt[k - 1];
+                start = cnt;
+                items.assign((size_t)total, 0);
+                std::vector<uint32_t> cur(start.begin(), start.end() - 1);
+                for (int32_t i : small) {  // ascending ids: every cell's list comes out ascending
+                    int x0, x1, y0, y1, z0, z1;
+                    range(i, 0, x0, x1); range(i, 1, y0, y1); range(i, 2, z0, z1);
+                    for (int z = z0; z <= z1; z++) for (int y = y0; y <= y1; y++) for (int x = x0; x <= x1; x++) items[cur[(size_t)((z * dims[1] + y) * dims[0] + x)]++] = i;
+                }
+                break;
+            }
+        }
+        cell *= 1.5;
+    }
+    int32_t* d_big = nullptr; uint32_t* d_start = nullptr; int32_t* d_items = nullptr;
+    int rc;
+    if ((rc = dev_alloc(c, &d_big, big.size(), false)) || (rc = dev_alloc(c, &d_start, start.size(), false)) || (rc = dev_alloc(c, &d_items, items.size(), false))) return rc;
+    if (!big.empty()) HIPCHK(hipMemcpy(d_big, big.data(), big.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_start, start.data(), start.size() * 4, hipMemcpyHostToDevice));
+    if (!items.empty()) HIPCHK(hipMemcpy(d_items, items.data(), items.size() * 4, hipMemcpyHostToDevice));
+    DevScene& g = c->dscene;
+    g.n_cells = dims[0] * dims[1] * dims[2]; g.n_big = (int)big.size(); g.gx = dims[0]; g.gy = dims[1]; g.gz = dims[2];
+    for (int a = 0; a < 3; a++) g.g_lo[a] = lo[a];
+    g.g_cell = cell; g.g_inv = 1.0 / cell;
+    g.big = d_big; g.cell_start = d_start; g.cell_items = d_items;
+    if (getenv("SPPM_DEBUG"))
+        fprintf(stderr, "[sppm] scene grid: %d spheres, %zu big, %dx%dx%d cells of %.3f, %zu list entries\n", n, big.size(), dims[0], dims[1], dims[2], cell, items.size());
+    return 0;
+}
+
 static void set_cur(sppm_ctx* c, int b);
 static int ppm_prepare(sppm_ctx* c);
 
 extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres, int32_t n_spheres, void* stream, sppm_ctx** out)
 {
     if (!cfg || !h_spheres || !out || n_spheres < 1) return fail(SPPM_ERR_INVALID, "sppm_create: null argument or empty scene");
-    if (n_spheres > SPPM_MAX_SPHERES) return fail(SPPM_ERR_INVALID, "sppm_create: more than 512 spheres (the brute-force sphere table lives in LDS; larger scenes need a ray acceleration structure, not built yet)");
+    if (n_spheres > SPPM_MAX_SPHERES_GRID) return fail(SPPM_ERR_INVALID, "sppm_create: more than 2^20 spheres");
     if (cfg->width < 1 || cfg->height < 1 || cfg->samples < 1 || cfg->supersamples < 1)
         return fail(SPPM_ERR_INVALID, "sppm_create: width, height, samples, supersamples must be >= 1");
     if ((int64_t)cfg->width * cfg->height > (1ll << 30)) return fail(SPPM_ERR_INVALID, "sppm_create: image too large");
@@ -1364,6 +1446,9 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
     if (hipMemcpyAsync(c->d_spheres, h_spheres, sizeof(sppm_sphere) * (size_t)n_spheres, hipMemcpyHostToDevice, c->stream) != hipSuccess) {
         sppm_destroy(c); return fail(SPPM_ERR_HIP, "copying the scene failed");
     }
+    memset(&c->dscene, 0, sizeof c->dscene);
+    c->dscene.sp = c->d_spheres; c->dscene.ns = n_spheres;
+    if (n_spheres > SPPM_MAX_SPHERES || env_i64("SPPM_SCENE_GRID", 0)) TRY(build_scene_grid(c, h_spheres, n_spheres));
     {   // PinholeCamera constructor, src/cameras.h:34-50
         double sxn[3], cx[3], sx[3], sy[3], cy[3], syn[3], center[3];
         const double screen_width = cfg->screen_height * (double)cfg->width / (double)cfg->height;
@@ -1529,8 +1614,8 @@ extern "C" int sppm_destroy(sppm_ctx* c)
     return SPPM_OK;
 }
 
-static inline DevScene scene_of(const sppm_ctx* c) { DevScene s; s.sp = c->d_spheres; s.ns = c->ns; return s; }
-static inline size_t scene_lds(const sppm_ctx* c) { return (size_t)c->ns * sizeof(sppm_sphere); }  // dynamic LDS of STAGE_SCENE
+static inline DevScene scene_of(const sppm_ctx* c) { return c->dscene; }
+static inline size_t scene_lds(const sppm_ctx* c) { return c->dscene.n_cells ? 0 : (size_t)c->ns * sizeof(sppm_sphere); }  // dynamic LDS of STAGE_SCENE
 static inline int nblk(int64_t n, int b) { return (int)((n + b - 1) / b); }
 static inline double reach_of(const sppm_ctx* c) { return std::sqrt(c->cfg.gather_radius2) * (1.0 + 1e-9) + 1e-9; }
 // the occupancy map of the CURRENT view (valid on the context's stream once the eye pass is ordered before it)
