@@ -29,18 +29,18 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
-def cpu_baseline(width, height, photons, seconds_target=12.0):
+def cpu_baseline(width, height, photons, seconds_target=12.0, table=None):
     """The oracle (a faithful single-thread port of the reference's kd-tree SPPM) on this box's host
     cores: eye pass 0 + kd build + a bounded number of photons of pass 0, same workload geometry."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as ol
     from raytracer_amd.scene import CORNELL_SPHERES
     par = ol.make_params(width, height, sampler=1, math=1, photons_per_pass=photons)
-    orc = ol.Oracle(par, ol.make_spheres(CORNELL_SPHERES))
+    orc = ol.Oracle(par, ol.make_spheres(table if table is not None else CORNELL_SPHERES))
     t0 = time.perf_counter()
     orc.eye_pass(0)
     t_eye = time.perf_counter() - t0
-    n, done, t_ph = 2000, 0, 0.0
+    n, done, t_ph = 2000 if table is None else 100, 0, 0.0
     while t_ph < seconds_target and done < photons:
         n = min(n, photons - done)
         t0 = time.perf_counter()
@@ -173,6 +173,8 @@ def main():
     ap.add_argument("--photons", type=int, default=1_000_000, help="photons per pass per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", choices=("sppm", "ppm"), default="sppm", help="sppm: BASELINE config 2/3 (the metric's workload); ppm: config 4, classic PPM")
+    ap.add_argument("--spheres", type=int, default=0, help="sppm workload: N > 0 replaces the Cornell scene by raytracer_amd.scene.synthetic_spheres(N) "
+                    "(BASELINE config 5: --spheres 10000 --width 3840 --height 2160); rays then walk a grid over the spheres")
     ap.add_argument("--supersamples", type=int, default=1, help="--workload ppm only")
     ap.add_argument("--radius2", type=float, default=5.0, help="--workload ppm only: InitialRadius = gather radius (squared), src/main.cpp:76-77")
     args = ap.parse_args()
@@ -206,6 +208,9 @@ def main():
     from raytracer_amd.parallel import ShardedSppm
 
     W, H, M = args.width, args.height, args.photons
+    from raytracer_amd import scene
+    table = scene.synthetic_spheres(args.spheres) if args.spheres > 0 else scene.CORNELL_SPHERES
+    scene_name = f"{args.spheres}-sphere synthetic scene (scene.synthetic_spheres, seed 20260517) in the Cornell box" if args.spheres > 0 else "Cornell-box"
 
     def barrier():
         if world > 1:
@@ -213,13 +218,13 @@ def main():
         torch.cuda.synchronize()
 
     if args.warmup > 0:  # untimed: a scratch render of W passes
-        scratch = ShardedSppm(W, H, photons_per_rank=M, rank=rank, world=world)
+        scratch = ShardedSppm(W, H, photons_per_rank=M, rank=rank, world=world, spheres=table)
         scratch.total_passes = args.warmup
         for i in range(args.warmup):
             scratch.step(i)
         scratch.ctx.check()
         scratch.close()
-    job = ShardedSppm(W, H, photons_per_rank=M, rank=rank, world=world)
+    job = ShardedSppm(W, H, photons_per_rank=M, rank=rank, world=world, spheres=table)
     job.total_passes = args.steps
     job.ctx.set_timing(True)
     c0 = job.ctx.counters()
@@ -263,7 +268,7 @@ def main():
             "value": photons_total / dt, "unit": "photons/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"Cornell-box SPPM {W}x{H}, {M} photons/pass/GPU, passes 0..{args.steps - 1} "
+            "config": {"workload": f"{scene_name} SPPM {W}x{H}, {M} photons/pass/GPU, passes 0..{args.steps - 1} "
                                    f"of a fresh render, alpha 0.7, initial r^2 25, search r^2 25, per-photon update (sppm2.h), "
                                    f"XorShift streams", "photons_per_pass": M * world, "width": W, "height": H,
                        "parallelism": job.describe()},
@@ -283,8 +288,10 @@ def main():
                                  "rays_per_launch": p_rays / t_launch,
                                  "note": "rank 0; 219 flop per ray (20 x 9 spheres + 19, SURVEY 8d) x rays cast by photon tracing; overlapped with the gather"}
         out["roofline"]["traffic"] = measured_traffic(W, H, M, args.steps)
+        if args.spheres > 0:
+            out["roofline_trace"]["note"] = "rank 0; rays cast by photon tracing; the flop figure prices a ray at the Cornell scene's 219 flop (a grid walk tests fewer spheres per ray than brute force, so this is not a flop count for this scene)"
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(W, H, M)
+            out["cpu_baseline"] = cpu_baseline(W, H, M, table=table)
         print(json.dumps(out), flush=True)
     job.close()
     if world > 1:

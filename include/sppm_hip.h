@@ -122,7 +122,9 @@ int sppm_device_count(void);
 /* Replaces constructing StochasticPpm<W,H>(samples, supersamples) (src/sppm2.h:90-97) plus the
  * allocations at the top of render() (src/sppm2.h:581,615-619).  `stream` is a hipStream_t (NULL =
  * the default stream).  The scene is copied to the device (the reference compiles it in,
- * src/scene.h:12-24). */
+ * src/scene.h:12-24); sphere 0 is the light (LightID, src/sppm2.h:132).  Up to 512 spheres the closest
+ * hit is the reference's loop over all spheres (src/scene.h:53-76); above that (at most 2^20) it walks a
+ * uniform grid over the small spheres and returns the same sphere and distance, bit for bit. */
 int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres, int32_t n_spheres, void* stream, sppm_ctx** out);
 int sppm_destroy(sppm_ctx* ctx);
 
