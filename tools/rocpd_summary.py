@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Summaries of rocprofv3's rocpd (.db) output, the format this ROCm writes by default.
+
+    rocpd_summary.py stats  RESULTS.db OUT.csv                      kernel statistics (what --stats prints)
+    rocpd_summary.py pmc    FETCH.db WRITE.db W H PHOTONS STEPS     -> profiles/r01_pmc_traffic.json
+
+FETCH_SIZE / WRITE_SIZE are in KiB (rocprofv3 derived counters); FETCH_SIZE is doubled, the gfx950 correction of
+/opt/skills/guides/MI355X_MICROARCH.md (HBM section).  Each counter comes from a run of its own."""
+import collections
+import csv
+import json
+import sqlite3
+import statistics
+import sys
+
+
+def short(name):
+    return name.split("(")[0].replace("void ", "")
+
+
+def stats(db_path, out_csv):
+    db = sqlite3.connect(db_path)
+    d = collections.defaultdict(list)
+    for name, dur in db.execute("select name, duration from kernels"):
+        d[name].append(dur)
+    total = sum(sum(v) for v in d.values())
+    with open(out_csv, "w", newline="") as f:
+        w = csv.writer(f, quoting=csv.QUOTE_NONNUMERIC)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
+        for name, v in sorted(d.items(), key=lambda kv: -sum(kv[1])):
+            n = name if len(name) < 200 else short(name)[:160] + "<...>"
+            w.writerow([n, len(v), sum(v), round(sum(v) / len(v), 3), round(100.0 * sum(v) / total, 2), min(v), max(v),
+                        round(statistics.pstdev(v), 3)])
+
+
+def per_kernel(db_path, counter):
+    db = sqlite3.connect(db_path)
+    tot, calls = collections.defaultdict(float), collections.Counter()
+    for name, val in db.execute("select kernel_name, value from counters_collection where counter_name = ?", (counter,)):
+        tot[short(name)] += val
+        calls[short(name)] += 1
+    return tot, calls
+
+
+def pmc(fetch_db, write_db, w, h, m, steps):
+    fetch, fc = per_kernel(fetch_db, "FETCH_SIZE")
+    write, wc = per_kernel(write_db, "WRITE_SIZE")
+    rows = {}
+    for k in sorted(set(fetch) | set(write), key=lambda k: -(fetch.get(k, 0) + write.get(k, 0))):
+        if len(k) > 120:
+            continue
+        rows[k] = {"launches": fc.get(k, wc.get(k)), "fetch_bytes_per_launch": 2 * 1024 * fetch.get(k, 0) / max(1, fc.get(k, 0)),
+                   "write_bytes_per_launch": 1024 * write.get(k, 0) / max(1, wc.get(k, 0))}
+    g = next(v for k, v in rows.items() if k.startswith("k_gather_tiles"))
+    out = {"width": w, "height": h, "photons": m, "steps": steps,
+           "gather_bytes_per_launch": g["fetch_bytes_per_launch"] + g["write_bytes_per_launch"],
+           "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs of bench.py; KiB -> bytes; FETCH_SIZE x2 (gfx950)",
+           "kernels": rows}
+    json.dump(out, open("profiles/r01_pmc_traffic.json", "w"), indent=1)
+    print(json.dumps({"gather_bytes_per_launch": out["gather_bytes_per_launch"], "launches": g["launches"]}))
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "stats":
+        stats(sys.argv[2], sys.argv[3])
+    else:
+        pmc(sys.argv[2], sys.argv[3], *[int(x) for x in sys.argv[4:8]])
