@@ -210,10 +210,19 @@ __device__ __forceinline__ bool intersect_scene_grid(const DevScene& sc, d3 org,
     return true;
 }
 
+// GRID 0: the brute-force loop (small scene, staged in LDS); 1: the grid; 2: whichever the scene has.  The
+// kernels that set the frame time are compiled for 0 and 1 separately, so that the small-scene path carries
+// none of the grid walk's registers.
+#define SCENE_ANY 2
+template <int GRID = SCENE_ANY>
 __device__ __forceinline__ bool intersect_scene(const DevScene& sc, d3 org, d3 dir, Hit& h)
 {
-    if (sc.n_cells > 0) return intersect_scene_grid(sc, org, dir, h);
-    return intersect_scene(sc.sp, sc.ns, org, dir, h);
+    if constexpr (GRID == 0) return intersect_scene(sc.sp, sc.ns, org, dir, h);
+    else if constexpr (GRID == 1) return intersect_scene_grid(sc, org, dir, h);
+    else {
+        if (sc.n_cells > 0) return intersect_scene_grid(sc, org, dir, h);
+        return intersect_scene(sc.sp, sc.ns, org, dir, h);
+    }
 }
 
 // Copies the sphere table (88-byte rows = 11 doubles) into dynamic LDS and points `sc` at the copy (small
@@ -224,6 +233,15 @@ __device__ __forceinline__ bool intersect_scene(const DevScene& sc, d3 org, d3 d
 #define STAGE_SCENE(sc)                                                                                              \
     extern __shared__ __align__(16) double s_scene_dyn[];                                                             \
     if ((sc).n_cells == 0) {                                                                                          \
+        for (int i_ = threadIdx.x; i_ < (sc).ns * 11; i_ += blockDim.x) s_scene_dyn[i_] = ((const double*)(sc).sp)[i_]; \
+        __syncthreads();                                                                                              \
+        (sc).sp = (const sppm_sphere*)s_scene_dyn;                                                                    \
+    }
+// The same in a kernel compiled for one kind of scene: with GRID == 0 the pointer is known to be an LDS
+// address from here on (LDS reads instead of flat ones in the sphere loop), with GRID == 1 nothing is staged.
+#define STAGE_SCENE_T(sc, GRID)                                                                                      \
+    extern __shared__ __align__(16) double s_scene_dyn[];                                                             \
+    if constexpr ((GRID) == 0) {                                                                                      \
         for (int i_ = threadIdx.x; i_ < (sc).ns * 11; i_ += blockDim.x) s_scene_dyn[i_] = ((const double*)(sc).sp)[i_]; \
         __syncthreads();                                                                                              \
         (sc).sp = (const sppm_sphere*)s_scene_dyn;                                                                    \
@@ -330,7 +348,7 @@ __device__ __forceinline__ d3 cosine_sampling(d3 w, d3 u, d3 v, RNG& rng)
 }
 
 // next_event_est, src/radiance.h:29-70
-template <class RNG>
+template <class RNG, int GRID = SCENE_ANY>
 __device__ __forceinline__ d3 next_event_est(const DevScene& sc, const Hit& is, d3 on,
                                              RNG& rng, uint32_t& rays)
 {
@@ -352,7 +370,7 @@ __device__ __forceinline__ d3 next_event_est(const DevScene& sc, const Hit& is, 
     const double radius2 = sp[0].radius * sp[0].radius;
     Hit sh;
     rays++;
-    const bool hit = intersect_scene(sc, is.position, ldir, sh);
+    const bool hit = intersect_scene<GRID>(sc, is.position, ldir, sh);
     if (hit && sh.object_id == 0 && dot1 < 0 && dot0 > 0) {
         const double G = (fabs(dot0) * fabs(dot1)) / dist2;
         const double pdf = 1.0 / (4.0 * SPPM_PI * radius2);

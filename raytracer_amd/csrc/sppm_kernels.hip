@@ -98,7 +98,7 @@ __device__ __forceinline__ LensRng make_lens(const EyeParams& ep, int t, int ind
 // One pixel of an eye pass: the sy/sx/s loops of src/sppm2.h:628-643 around create_point_loop
 // (:156-315).  t = y*W + x is the pixel's place in the reference's render order.  COMMIT = false runs
 // the same paths without storing anything (used to count draws).
-template <class RNG, bool COMMIT>
+template <class RNG, bool COMMIT, int GRID = SCENE_ANY>
 __device__ __forceinline__ void eye_pixel(const DevScene& sc, const EyeParams& ep, const HpArrays& hp, const HpArrays& out, int t, RNG& rng, uint32_t& rays)
 {
     const int P = ep.W * ep.H;
@@ -121,7 +121,7 @@ __device__ __forceinline__ void eye_pixel(const DevScene& sc, const EyeParams& e
                     depth++;
                     Hit is;
                     rays++;
-                    if (!intersect_scene(sc, org, dir, is)) break;
+                    if (!intersect_scene<GRID>(sc, org, dir, is)) break;
                     const sppm_sphere* obj = &sc.sp[is.object_id];
                     const d3 color = ld3(obj->color);
                     const int type = obj->reflection_type;
@@ -129,7 +129,7 @@ __device__ __forceinline__ void eye_pixel(const DevScene& sc, const EyeParams& e
                     if (direct) ld = ld + had(weight, ld3(obj->emission));
                     direct = type != SPPM_DIFFUSE;
                     if (type == SPPM_DIFFUSE) {
-                        const d3 est = next_event_est(sc, is, on, rng, rays);
+                        const d3 est = next_event_est<RNG, GRID>(sc, is, on, rng, rays);
                         ld = ld + had(weight, est);
                         // create or overwrite the pixel's hitpoint (src/sppm2.h:204-227)
                         if constexpr (COMMIT) {
@@ -211,16 +211,17 @@ __device__ __forceinline__ void eye_pixel(const DevScene& sc, const EyeParams& e
 }
 
 // One thread per pixel, one XorShift stream per (pass, image index).
+template <int GRID>
 __global__ void __launch_bounds__(256) k_eye_pass(DevScene sc, EyeParams ep, HpArrays hp, HpArrays out, unsigned long long* __restrict__ counters)
 {
-    STAGE_SCENE(sc);
+    STAGE_SCENE_T(sc, GRID);
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int P = ep.W * ep.H;
     uint32_t rays = 0;
     if (t < P) {
         const int index = (ep.H - t / ep.W - 1) * ep.W + t % ep.W;
         XorShift rng = make_stream(ep.seed_eye, (uint64_t)ep.pass * (uint64_t)P + (uint64_t)index);
-        eye_pixel<XorShift, true>(sc, ep, hp, out, t, rng, rays);
+        eye_pixel<XorShift, true, GRID>(sc, ep, hp, out, t, rng, rays);
     }
     // rays counter: one atomic per wave
     for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off);
@@ -520,14 +521,14 @@ __device__ __forceinline__ void photon_emit(const DevScene& sc, const TraceParam
 }
 
 // one iteration of the while loop of create_photon; returns false when the path ends
-template <class RNG>
+template <class RNG, int GRID>
 __device__ __forceinline__ bool photon_bounce(const DevScene& sc, PhotonState<RNG>& ps, Deposit& dep, int32_t* __restrict__ err, uint32_t& rays, const bool ppm)
 {
     if (ps.rng.stop()) return false;
     if (max3(ps.flux) <= 0.0) return false;
     Hit is;
     rays++;
-    if (!intersect_scene(sc, ps.org, ps.dir, is)) return false;
+    if (!intersect_scene<GRID>(sc, ps.org, ps.dir, is)) return false;
     const sppm_sphere* obj = &sc.sp[is.object_id];
     const d3 color = ld3(obj->color);
     const int type = obj->reflection_type;
@@ -570,13 +571,13 @@ template <> struct TraceRng<0> { typedef XorShift type; };
 #define TRACE_GRAB 64
 #define REC_CHUNK 128  // record slots a wavefront reserves at a time (one atomic per chunk instead of one per record)
 #define REC_INVALID (~0ull)
-template <int MODE>
+template <int MODE, int GRID>
 __global__ void __launch_bounds__(256) k_photon_trace(DevScene sc, TraceParams tp, RecArrays rec, unsigned long long* __restrict__ rec_count,
                                                       unsigned long long* __restrict__ next_block, unsigned long long* __restrict__ counters,
                                                       int32_t* __restrict__ err)
 {
     typedef typename TraceRng<MODE>::type RNG;
-    STAGE_SCENE(sc);
+    STAGE_SCENE_T(sc, GRID);
     const int lane = threadIdx.x & 63;
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     uint32_t rays = 0;
@@ -607,7 +608,7 @@ __global__ void __launch_bounds__(256) k_photon_trace(DevScene sc, TraceParams t
         Deposit dep;
         dep.want = false;
         if (active) {
-            active = photon_bounce(sc, ps, dep, err, rays, tp.ppm != 0);
+            active = photon_bounce<RNG, GRID>(sc, ps, dep, err, rays, tp.ppm != 0);
             if constexpr (MODE == 2)
                 if (!active) tp.consumed[ps.index] = ps.rng.stop() ? STREAM_OVER : (uint32_t)(ps.rng.pos - ps.index);
             if constexpr (MODE == 1)
@@ -1806,7 +1807,9 @@ static int prepare_photon_stream(sppm_ctx* c, int32_t pass, int64_t count)
         tp.pass = pass; tp.first = 0; tp.count = len; tp.photons_per_pass = c->cfg.photons_per_pass; tp.seed_photon = c->cfg.seed_photon;
         tp.flux_scale = c->flux_scale; tp.rec_cap = 0; tp.u = c->d_u_ph; tp.u_len = len; tp.start = nullptr; tp.consumed = c->d_ph_consumed; tp.ppm = c->algo;
         const int blocks = (int)std::min<int64_t>(nblk(len, 256), 256 * 4);
-        hipLaunchKernelGGL(k_photon_trace<2>, dim3(blocks), dim3(256), scene_lds(c), st, scene_of(c), tp, c->rec_buf[c->cur], c->d_rec_count_buf[c->cur],
+        if (c->dscene.n_cells) hipLaunchKernelGGL((k_photon_trace<2, 1>), dim3(blocks), dim3(256), scene_lds(c), st, scene_of(c), tp, c->rec_buf[c->cur], c->d_rec_count_buf[c->cur],
+                           c->d_trace_next_buf[c->cur], c->d_counters, c->d_err);
+        else hipLaunchKernelGGL((k_photon_trace<2, 0>), dim3(blocks), dim3(256), scene_lds(c), st, scene_of(c), tp, c->rec_buf[c->cur], c->d_rec_count_buf[c->cur],
                            c->d_trace_next_buf[c->cur], c->d_counters, c->d_err);
         hipLaunchKernelGGL(k_photon_chain, dim3(1), dim3(64), 0, st, c->d_ph_consumed, len, count, c->d_ph_start, c->d_stream_total, c->d_err);
         HIPCHK(hipGetLastError());
@@ -1838,7 +1841,8 @@ static int eye_launch(sppm_ctx* c, int32_t pass, hipStream_t st)
         int rc = eye_pass_stream(c, ep);  // host-driven, on the context's stream
         if (rc) return rc;
     } else {
-        hipLaunchKernelGGL(k_eye_pass, dim3(nblk(c->P, 256)), dim3(256), scene_lds(c), st, scene_of(c), ep, c->hp, c->view[nv], c->d_counters);
+        if (c->dscene.n_cells) hipLaunchKernelGGL(k_eye_pass<1>, dim3(nblk(c->P, 256)), dim3(256), scene_lds(c), st, scene_of(c), ep, c->hp, c->view[nv], c->d_counters);
+        else hipLaunchKernelGGL(k_eye_pass<0>, dim3(nblk(c->P, 256)), dim3(256), scene_lds(c), st, scene_of(c), ep, c->hp, c->view[nv], c->d_counters);
         HIPCHK(hipGetLastError());
     }
     if (c->gather_mode && c->n_own_pix > 0) {
@@ -1945,9 +1949,12 @@ static int trace_into(sppm_ctx* c, int b, int32_t pass, int64_t first, int64_t c
     if (c->sampler == 1) {
         if (c->stream_pass != pass) return fail(SPPM_ERR_STATE, "reference-stream mode: the pass's stream offsets are made by sppm_photon_pass(pass, 0, photons)");
         tp.u = c->d_u_ph; tp.u_len = c->stream_len; tp.start = c->d_ph_start;
-        hipLaunchKernelGGL(k_photon_trace<1>, dim3(trace_blocks), dim3(256), scene_lds(c), st, scene_of(c), tp, c->rec_buf[b], c->d_rec_count_buf[b], c->d_trace_next_buf[b], c->d_counters, c->d_err);
-    } else
-        hipLaunchKernelGGL(k_photon_trace<0>, dim3(trace_blocks), dim3(256), scene_lds(c), st, scene_of(c), tp, c->rec_buf[b], c->d_rec_count_buf[b], c->d_trace_next_buf[b], c->d_counters, c->d_err);
+        if (c->dscene.n_cells) hipLaunchKernelGGL((k_photon_trace<1, 1>), dim3(trace_blocks), dim3(256), scene_lds(c), st, scene_of(c), tp, c->rec_buf[b], c->d_rec_count_buf[b], c->d_trace_next_buf[b], c->d_counters, c->d_err);
+        else hipLaunchKernelGGL((k_photon_trace<1, 0>), dim3(trace_blocks), dim3(256), scene_lds(c), st, scene_of(c), tp, c->rec_buf[b], c->d_rec_count_buf[b], c->d_trace_next_buf[b], c->d_counters, c->d_err);
+    } else {
+        if (c->dscene.n_cells) hipLaunchKernelGGL((k_photon_trace<0, 1>), dim3(trace_blocks), dim3(256), scene_lds(c), st, scene_of(c), tp, c->rec_buf[b], c->d_rec_count_buf[b], c->d_trace_next_buf[b], c->d_counters, c->d_err);
+        else hipLaunchKernelGGL((k_photon_trace<0, 0>), dim3(trace_blocks), dim3(256), scene_lds(c), st, scene_of(c), tp, c->rec_buf[b], c->d_rec_count_buf[b], c->d_trace_next_buf[b], c->d_counters, c->d_err);
+    }
     if (c->timing) { HIPCHK(hipEventRecord(e1, st)); c->ev_trace.push_back({e0, e1}); }
     HIPCHK(hipGetLastError());
     c->photons_traced += (uint64_t)count;
