@@ -124,3 +124,28 @@ def test_many_spheres_classic_ppm_and_reference_stream():
 def test_sphere_count_limit():
     with pytest.raises(capi.SppmError):
         sppm.SppmContext(sppm.make_config(8, 8), spheres=[CORNELL_SPHERES[0]] * ((1 << 20) + 1))
+
+
+def test_grid_without_walls_and_empty_views():
+    """Edge cases: a scene of equal spheres and nothing else (no 'big' sphere, most rays leave the grid and hit
+    nothing), and cameras that see nothing at all (SPPM: no pixel owns a hitpoint; classic PPM: an empty list)."""
+    table = [t for t in scene.synthetic_spheres(700, radius=(0.8, 0.8)) if t[0] < 100.0]  # drops the walls, keeps the light
+    ctx = sppm.SppmContext(sppm.make_config(32, 24, photons_per_pass=2000), spheres=table)
+    ids = _first_hits(ctx, table, _random_rays(100_000, 3), "no walls")
+    assert (ids < 0).mean() > 0.2 and (ids >= 0).mean() > 0.02
+    orc = ol.Oracle(ol.make_params(32, 24, sampler=1, math=1, photons_per_pass=2000), ol.make_spheres(table))
+    _passes(ctx, orc, 2000, 2, "no walls")
+    ctx.close()
+    lonely = [(1.0, (50.0, 52.0, 400.0), (10.0, 10.0, 10.0), (0.9, 0.9, 0.9), scene.DIFFUSE)]  # one light behind the camera
+    for algo in (0, 1):
+        ctx = sppm.SppmContext(sppm.make_config(32, 24, photons_per_pass=1000, algorithm=algo), spheres=lonely)
+        assert ctx.n_hitpoints == (0 if algo == 1 else 32 * 24)
+        ctx.eye_pass(0)
+        ctx.photon_pass(0, 1000)
+        ctx.end_pass()
+        img = ctx.resolve(0, 1000).cpu().numpy()
+        ctx.check()
+        assert (img == 0).all() and ctx.counters()["updates"] == 0
+        if algo == 0:
+            assert (ctx.hitpoints()["valid"] == 0).all()
+        ctx.close()
