@@ -31,10 +31,30 @@ def _rel_rmse(a, b):
     return float(np.sqrt(np.mean((a - b) ** 2)) / np.sqrt(np.mean(b ** 2)))
 
 
-def _pair(w, h, photons, ss, r2):
-    cfg = sppm.make_config(w, h, supersamples=ss, photons_per_pass=photons, gather_radius2=r2, initial_radius2=r2, algorithm=1)
-    par = ol.make_params(w, h, supersamples=ss, sampler=1, math=1, photons_per_pass=photons, gather_radius2=r2, initial_radius2=r2)
+def _pair(w, h, photons, ss, r2, samples=1):
+    cfg = sppm.make_config(w, h, samples=samples, supersamples=ss, photons_per_pass=photons, gather_radius2=r2, initial_radius2=r2, algorithm=1)
+    par = ol.make_params(w, h, samples=samples, supersamples=ss, sampler=1, math=1, photons_per_pass=photons, gather_radius2=r2, initial_radius2=r2)
     return sppm.SppmContext(cfg), ol.PpmOracle(par, ol.make_spheres(CORNELL_SPHERES))
+
+
+def test_classic_ppm_repeated_samples():
+    """samples > 1 repeats one ray per sub-pixel (src/progressive_photonmapping.h:774-788; src/main.cpp:74 runs 100): where no
+    draw steers the path the hitpoints coincide, each with a state of its own, and the image divides by spp."""
+    w, h, photons = 40, 30, 15000
+    ctx, orc = _pair(w, h, photons, 1, 25.0, samples=3)
+    assert ctx.n_hitpoints == orc.eye_pass() and ctx.n_hitpoints >= 3 * w * h * 0.9
+    ctx.eye_pass(0)
+    ctx.photon_pass(0, photons)
+    orc.photon_pass(0, photons)
+    ctx.check()
+    s, o = ctx.hitpoints(), orc.state()
+    _same(s["hp_f"][:, :8], o["hp_f"][:, :8], "hitpoint list")
+    dup = (o["hp_f"][1:, 1:4] == o["hp_f"][:-1, 1:4]).all(axis=1).mean()
+    assert dup > 0.5, "most consecutive hitpoints coincide"
+    for k in ("n", "r2", "flux"):
+        _same(s[k], o[k], f"state {k}")
+    _same(ctx.resolve(0, photons).cpu().numpy(), orc.resolve(photons, order=1), "image")
+    ctx.close()
 
 
 @pytest.mark.parametrize("w,h,ss,r2,photons", [(64, 48, 1, 25.0, 20000), (48, 36, 2, 5.0, 30000)])
