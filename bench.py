@@ -80,72 +80,82 @@ def cpu_baseline_ppm(width, height, photons, r2, seconds_target=12.0):
                       f"{done} photons in {t_ph:.1f} s, {upd} hitpoint updates ({upd / t_ph:.3g} updates/s)"}
 
 
-def main_ppm(args):
+def main_ppm(args, rank, world, barrier):
     """--workload ppm: BASELINE config 4, classic progressive photon mapping (src/progressive_photonmapping.h) at
-    1080p on one GPU.  A step is one batch of --photons photons applied to the fixed hitpoint list; the timed
-    region is a whole render: the eye pass that stores the list, K batches, the image.  (sppm_create, outside
-    the region as for the SPPM workload, traces the eye paths once to size the list: reported as create_ms.)"""
+    1080p.  A step is one batch of --photons photons per GPU applied to the fixed hitpoint list; the timed region
+    is a whole render: the eye pass that stores the list, K batches, (N > 1: the all-reduce of the owned hitpoint
+    state,) the image.  (sppm_create, outside the region as for the SPPM workload, traces the eye paths once to
+    size the list: reported as create_ms.)  N > 1: the list is shared out by ranges of its Morton order, records
+    by all-gather, as for SPPM (raytracer_amd.parallel.ShardedPpm)."""
     import torch
-    from raytracer_amd import sppm
-    if int(os.environ.get("WORLD_SIZE", "1")) != 1 or args.gpus != 1:
-        sys.exit("--workload ppm runs on one GPU (replicas only)")
-    torch.cuda.set_device(0)
+    import torch.distributed as dist
+    from raytracer_amd.parallel import ShardedPpm
     W, H, M, K = args.width, args.height, args.photons, args.steps
     r2 = args.radius2
-    total = M * K
+    total = M * K * world
 
-    def make(n):
-        return sppm.SppmContext(sppm.make_config(W, H, supersamples=args.supersamples, photons_per_pass=n, gather_radius2=r2,
-                                                 initial_radius2=r2, algorithm=1))
+    def make(steps):
+        return ShardedPpm(W, H, M, steps, rank=rank, world=world, supersamples=args.supersamples, gather_radius2=r2, initial_radius2=r2)
     if args.warmup > 0:
-        scratch = make(M * args.warmup)
-        scratch.eye_pass(0)
-        scratch.photon_pass(0, M * args.warmup)
-        scratch.check()
+        scratch = make(args.warmup)
+        for i in range(args.warmup):
+            scratch.step(i)
+        scratch.finish()
+        scratch.ctx.check()
         scratch.close()
-    torch.cuda.synchronize()
+    barrier()
     t0 = time.perf_counter()
-    ctx = make(total)
+    job = make(K)
     torch.cuda.synchronize()
     create_ms = 1e3 * (time.perf_counter() - t0)
+    ctx = job.ctx
     ctx.set_timing(True)
     c0 = ctx.counters()
-    torch.cuda.synchronize()
+    barrier()
     t0 = time.perf_counter()
-    ctx.eye_pass(0)
     for k in range(K):
-        ctx.photon_pass(0, M, first=k * M)
-    img = ctx.resolve(0, total)
+        job.step(k)
+    img = job.finish()
     ctx.check()
-    torch.cuda.synchronize()
+    barrier()
     dt = time.perf_counter() - t0
     c1 = ctx.counters()
-    g_ns = c1["gather_ns"] - c0["gather_ns"]
-    g_launch = max(1, c1["gather_launches"] - c0["gather_launches"])
-    cand, upd = c1["candidates"] - c0["candidates"], c1["updates"] - c0["updates"]
-    alg_bytes = 28.0 * cand + 32.0 * upd
-    achieved = alg_bytes / max(g_ns, 1) if g_ns else 0.0
-    out = {
-        "metric": "photons traced/sec + hitpoint updates/sec (whole node), classic PPM Cornell 1080p",
-        "value": total / dt, "unit": "photons/s", "n_gpus": 1, "steps": K, "warmup": args.warmup, "ms_per_step": 1e3 * dt / K,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"Cornell-box classic PPM {W}x{H}, supersamples {args.supersamples}, {ctx.n_hitpoints} fixed hitpoints, "
-                               f"{K} batches of {M} photons, alpha 0.7, initial r^2 = search r^2 = {r2:g} (src/main.cpp:76-77), XorShift streams",
-                   "photons": total, "width": W, "height": H, "hitpoints": ctx.n_hitpoints, "parallelism": "1 GPU"},
-        "create_ms": create_ms, "hitpoint_updates_per_s": upd / dt, "updates_per_photon": upd / total,
-        "records_per_photon": (c1["records"] - c0["records"]) / total,
-        "trace": {"kernel": "k_photon_trace", "launches": int(c1["trace_launches"] - c0["trace_launches"]),
-                  "avg_launch_ms": (c1["trace_ns"] - c0["trace_ns"]) / 1e6 / max(1, c1["trace_launches"] - c0["trace_launches"]),
-                  "note": "on its own stream, overlapped with the gather of the batch before"},
-        "roofline": {"bound": "hbm", "kernel": "k_gather_tiles", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                     "traffic": None, "launches": int(g_launch), "avg_launch_ms": g_ns / 1e6 / g_launch, "alg_bytes_per_launch": alg_bytes / g_launch,
-                     "note": "algorithmic bytes = 28 B x (record, hitpoint) pairs distance-tested + 32 B x accepted updates (SURVEY 8d); launch durations from HIP events on the kernel's stream"},
-    }
-    assert bool(torch.isfinite(img).all())
-    if not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline_ppm(W, H, total, r2)
-    print(json.dumps(out), flush=True)
-    ctx.close()
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    d = torch.tensor([c1[k] - c0[k] for k in ("records", "candidates", "updates")], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(d, op=dist.ReduceOp.SUM)
+    dt = float(tmax.item())
+    records, _, upd_all = [float(x) for x in d.tolist()]
+    if rank == 0:
+        g_ns = c1["gather_ns"] - c0["gather_ns"]
+        g_launch = max(1, c1["gather_launches"] - c0["gather_launches"])
+        cand, upd = c1["candidates"] - c0["candidates"], c1["updates"] - c0["updates"]
+        alg_bytes = 28.0 * cand + 32.0 * upd
+        achieved = alg_bytes / max(g_ns, 1) if g_ns else 0.0
+        out = {
+            "metric": "photons traced/sec + hitpoint updates/sec (whole node), classic PPM Cornell 1080p",
+            "value": total / dt, "unit": "photons/s", "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": 1e3 * dt / K,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"Cornell-box classic PPM {W}x{H}, supersamples {args.supersamples}, {ctx.n_hitpoints} fixed hitpoints, "
+                                   f"{K} batches of {M} photons per GPU, alpha 0.7, initial r^2 = search r^2 = {r2:g} (src/main.cpp:76-77), XorShift streams",
+                       "photons": total, "width": W, "height": H, "hitpoints": ctx.n_hitpoints, "parallelism": job.describe()},
+            "create_ms": create_ms, "hitpoint_updates_per_s": upd_all / dt, "updates_per_photon": upd_all / total,
+            "records_per_photon": records / max(1.0, float(M) * K * (world if job.replicated_trace else 1)),
+            "trace": {"kernel": "k_photon_trace", "launches": int(c1["trace_launches"] - c0["trace_launches"]),
+                      "avg_launch_ms": (c1["trace_ns"] - c0["trace_ns"]) / 1e6 / max(1, c1["trace_launches"] - c0["trace_launches"]),
+                      "note": "rank 0; on its own stream, overlapped with the gather of the batch before"},
+            "roofline": {"bound": "hbm", "kernel": "k_gather_tiles", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                         "traffic": None, "launches": int(g_launch), "avg_launch_ms": g_ns / 1e6 / g_launch, "alg_bytes_per_launch": alg_bytes / g_launch,
+                         "note": "rank 0; algorithmic bytes = 28 B x (record, hitpoint) pairs distance-tested + 32 B x accepted updates (SURVEY 8d); launch durations from HIP events on the kernel's stream"},
+        }
+        assert bool(torch.isfinite(img).all())
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_ppm(W, H, total, r2)
+        print(json.dumps(out), flush=True)
+    job.close()
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def measured_traffic(width, height, photons, steps):
@@ -178,8 +188,6 @@ def main():
     ap.add_argument("--supersamples", type=int, default=1, help="--workload ppm only")
     ap.add_argument("--radius2", type=float, default=5.0, help="--workload ppm only: InitialRadius = gather radius (squared), src/main.cpp:76-77")
     args = ap.parse_args()
-    if args.workload == "ppm":
-        return main_ppm(args)
 
     if os.environ.get("SPPM_BENCH_PROGRESS"):  # diagnostics: where every rank is, every 30 s
         import faulthandler
@@ -204,6 +212,14 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if args.workload == "ppm":
+        return main_ppm(args, rank, world, barrier)
+
     from raytracer_amd import sppm
     from raytracer_amd.parallel import ShardedSppm
 
@@ -211,11 +227,6 @@ def main():
     from raytracer_amd import scene
     table = scene.synthetic_spheres(args.spheres) if args.spheres > 0 else scene.CORNELL_SPHERES
     scene_name = f"{args.spheres}-sphere synthetic scene (scene.synthetic_spheres, seed 20260517) in the Cornell box" if args.spheres > 0 else "Cornell-box"
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
 
     if args.warmup > 0:  # untimed: a scratch render of W passes
         scratch = ShardedSppm(W, H, photons_per_rank=M, rank=rank, world=world, spheres=table)

@@ -192,6 +192,14 @@ int sppm_save_ppm_file(const char* filename, const double* h_image, int32_t widt
 /* Waits for the context's stream and reports a deferred device-side error (record overflow, K cap). */
 int sppm_check(sppm_ctx* ctx);
 
+/* No counterpart in the reference: the hitpoint state between ranks.  d_out[P][5] (P = sppm_hitpoint_count) =
+ * (r^2, flux xyz, photon count) of the hitpoints this rank owns and zeros elsewhere; the sum over the ranks
+ * (one all-reduce; exactly one non-zero term per hitpoint, so it is exact) is the state of a single-GPU run,
+ * which sppm_import_state stores into every hitpoint.  After that sppm_resolve gives the full image on every
+ * rank (classic PPM sums several hitpoints per pixel, which different ranks may own).  update_rule 0. */
+int sppm_export_owned_state(sppm_ctx* ctx, double* d_out);
+int sppm_import_state(sppm_ctx* ctx, const double* d_in);
+
 /* Number of hitpoint slots: width*height for algorithm 0 (one per image index); the length of the
  * hitpoint list for algorithm 1 (point_map.GetData().size() after the loops of
  * src/progressive_photonmapping.h:760-793), known from sppm_create on. */

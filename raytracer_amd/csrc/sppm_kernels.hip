@@ -964,6 +964,32 @@ __global__ void __launch_bounds__(256) k_count_queries(HpArrays hp, RecArrays re
     }
 }
 
+// ---- hitpoint state between ranks ------------------------------------------------------------------------
+// out[h][5] = (r2, flux xyz, N) of the hitpoints this rank owns, zeros elsewhere: summed over the ranks (exactly
+// one non-zero term per hitpoint, so the sum is exact) it is the state of a single-GPU run.
+__global__ void k_export_state(HpArrays hp, Own own, double* __restrict__ out)
+{
+    const long long h = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long P = hp.P;
+    if (h >= P) return;
+    const bool mine = hp.valid[h] != 0 && owned(own, (int)h);
+    double* o = out + 5 * h;
+    o[0] = mine ? hp.r2[h] : 0.0;
+    o[1] = mine ? hp.flux[h] : 0.0; o[2] = mine ? hp.flux[P + h] : 0.0; o[3] = mine ? hp.flux[2 * P + h] : 0.0;
+    o[4] = mine ? (double)hp.n[h] : 0.0;
+}
+__global__ void k_import_state(HpArrays hp, const double* __restrict__ in)
+{
+    const long long h = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long P = hp.P;
+    if (h >= P) return;
+    if (!hp.valid[h]) return;
+    const double* o = in + 5 * h;
+    hp.r2[h] = o[0];
+    hp.flux[h] = o[1]; hp.flux[P + h] = o[2]; hp.flux[2 * P + h] = o[3];
+    hp.n[h] = (int32_t)o[4];
+}
+
 // end-of-pass update of rule 1, src/stochastic_ppm.h:721-741
 __global__ void k_end_pass(HpArrays hp, Own own, double alpha)
 {
@@ -1404,8 +1430,8 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
     if (cfg->ownership != 0 && cfg->ownership != 1) return fail(SPPM_ERR_INVALID, "sppm_create: ownership must be 0 (screen tiles) or 1 (ranges of the hitpoints' Morton order)");
     if (cfg->sampler != 0 && cfg->sampler != 1) return fail(SPPM_ERR_INVALID, "sppm_create: sampler must be 0 (XorShift streams) or 1 (reference mt19937 stream)");
     if (cfg->algorithm != 0 && cfg->algorithm != 1) return fail(SPPM_ERR_INVALID, "sppm_create: algorithm must be 0 (sppm2.h) or 1 (progressive_photonmapping.h)");
-    if (cfg->algorithm == 1 && (cfg->update_rule != 0 || cfg->tile_stride > 1 || cfg->ownership != 0))
-        return fail(SPPM_ERR_INVALID, "sppm_create: classic progressive photon mapping runs with update_rule 0 on one GPU (tile_stride <= 1, ownership 0)");
+    if (cfg->algorithm == 1 && (cfg->update_rule != 0 || (cfg->tile_stride > 1 && cfg->ownership != 1)))
+        return fail(SPPM_ERR_INVALID, "sppm_create: classic progressive photon mapping runs with update_rule 0; over several ranks its hitpoint list is shared out by ownership 1 (ranges of the Morton order)");
     if (cfg->camera_model != 0 && cfg->camera_model != 1) return fail(SPPM_ERR_INVALID, "sppm_create: camera_model must be 0 (pinhole) or 1 (thin lens)");
     if (cfg->camera_model == 1 && (cfg->algorithm != 0 || !(cfg->aperture >= 0.0) || !(cfg->focus_dist > 0.0)))
         return fail(SPPM_ERR_INVALID, "sppm_create: the thin-lens camera belongs to algorithm 0 and needs aperture >= 0 and focus_dist > 0");
@@ -2703,6 +2729,26 @@ extern "C" int sppm_owned_mask(sppm_ctx* c, uint8_t* d_mask)
     if (!c || !d_mask) return fail(SPPM_ERR_INVALID, "sppm_owned_mask: null argument");
     if (c->own_pending) return fail(SPPM_ERR_STATE, "sppm_owned_mask: spatial ownership is decided by the first eye pass");
     HIPCHK(hipMemcpyAsync(d_mask, c->d_own_mask, (size_t)c->P, hipMemcpyDeviceToDevice, c->stream));
+    return SPPM_OK;
+}
+
+extern "C" int sppm_export_owned_state(sppm_ctx* c, double* d_out)
+{
+    if (!c || !d_out) return fail(SPPM_ERR_INVALID, "sppm_export_owned_state: null argument");
+    if (c->cfg.update_rule != 0) return fail(SPPM_ERR_STATE, "sppm_export_owned_state: update_rule 0 only");
+    if (c->P == 0) return SPPM_OK;
+    hipLaunchKernelGGL(k_export_state, dim3(nblk(c->P, 256)), dim3(256), 0, c->stream, c->hp, own_of(c), d_out);
+    HIPCHK(hipGetLastError());
+    return SPPM_OK;
+}
+
+extern "C" int sppm_import_state(sppm_ctx* c, const double* d_in)
+{
+    if (!c || !d_in) return fail(SPPM_ERR_INVALID, "sppm_import_state: null argument");
+    if (c->cfg.update_rule != 0) return fail(SPPM_ERR_STATE, "sppm_import_state: update_rule 0 only");
+    if (c->P == 0) return SPPM_OK;
+    hipLaunchKernelGGL(k_import_state, dim3(nblk(c->P, 256)), dim3(256), 0, c->stream, c->hp, d_in);
+    HIPCHK(hipGetLastError());
     return SPPM_OK;
 }
 

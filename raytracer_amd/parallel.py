@@ -36,7 +36,7 @@ def owner_of_pixels(width, height, world):
 
 class ShardedSppm:
     def __init__(self, width, height, photons_per_rank, rank=0, world=1, exchange="allgather", ownership=1,
-                 spheres=scene.CORNELL_SPHERES, **cfg_kw):
+                 spheres=scene.CORNELL_SPHERES, photons_total=None, **cfg_kw):
         if exchange not in ("replicate", "allgather"):
             raise ValueError("exchange must be 'replicate' or 'allgather'")
         self.W, self.H, self.P = width, height, width * height
@@ -46,7 +46,8 @@ class ShardedSppm:
         self.exchange = exchange if world > 1 else "replicate"
         self.replicated_trace = self.exchange == "replicate"
         self.ownership = ownership
-        cfg = sppm.make_config(width, height, photons_per_pass=self.M, tile_first=rank, tile_stride=world, ownership=ownership, **cfg_kw)
+        # photons_total: the photon streams are keyed over this many photons (classic PPM: every step's photons belong to ONE run)
+        cfg = sppm.make_config(width, height, photons_per_pass=photons_total or self.M, tile_first=rank, tile_stride=world, ownership=ownership, **cfg_kw)
         self.ctx = sppm.SppmContext(cfg, spheres)
         self.image = None
         self._rows = self._all = self._side = self._next = None
@@ -88,10 +89,15 @@ class ShardedSppm:
             self._all = [torch.empty((self.world * cap, 10), dtype=torch.float64, device=dev) for _ in range(2)]
             self._side = torch.cuda.Stream(device=dev)
 
+    def _where(self, i):
+        """(pass, first photon) of step i: an SPPM step is a pass of its own"""
+        return i, 0
+
     def _start_block(self, i, done, n, buf):
         """trace this rank's block of the batch (and the eye pass of pass i, if it is the next one) on the context's
         look-ahead streams and pack it into rows[buf]"""
-        self.ctx.look_ahead_rows(i, done + self.rank * n, n, self._rows[buf])
+        p, base = self._where(i)
+        self.ctx.look_ahead_rows(p, base + done + self.rank * n, n, self._rows[buf])
 
     def _exchange(self, i, done, n, buf):
         """wait for the block's rows, then one all-gather (padded to the largest count) on the side stream"""
@@ -123,8 +129,9 @@ class ShardedSppm:
             ex, self._next = self._next, None
             torch.cuda.current_stream().wait_stream(self._side)
             rows, m = self._all[ex["buf"]], ex["m"]
+            base = self._where(i)[1]
             for r in range(self.world):
-                ctx.append_records(rows[r * m:(r + 1) * m], ex["counts"][r], done + r * n, done + (r + 1) * n)
+                ctx.append_records(rows[r * m:(r + 1) * m], ex["counts"][r], base + done + r * n, base + done + (r + 1) * n)
             self.applied += n * self.world
             done += n * self.world
             ni, ndone = (i, done) if done < self.M else (i + 1, 0)
@@ -148,6 +155,47 @@ class ShardedSppm:
 
     def close(self):
         self.ctx.close()
+
+
+class ShardedPpm(ShardedSppm):
+    """Classic progressive photon mapping (src/progressive_photonmapping.h) over ranks.  The hitpoint LIST is shared
+    out like SPPM's pixels (every rank traces the whole eye pass, then keeps a range of the list's Morton order);
+    a step is one batch of photons_per_rank x world photons of the single run of `steps` batches, exchanged like
+    SPPM's.  The image sums several hitpoints per pixel, which different ranks may own: finish() first sums the
+    ranks' owned state (one all-reduce, exact: one non-zero term per hitpoint) and resolves on every rank."""
+
+    def __init__(self, width, height, photons_per_rank, steps, rank=0, world=1, **kw):
+        kw.setdefault("gather_radius2", 5.0)
+        kw.setdefault("initial_radius2", kw["gather_radius2"])
+        super().__init__(width, height, photons_per_rank, rank=rank, world=world, ownership=1 if world > 1 else 0,
+                         photons_total=photons_per_rank * world * steps, algorithm=1, **kw)
+        self.steps = steps
+        self.total_passes = steps
+
+    def _where(self, i):
+        return 0, i * self.M
+
+    def step(self, i, resolve=False):
+        ctx = self.ctx
+        if i == 0:
+            ctx.eye_pass(0)
+        if self.replicated_trace:
+            ctx.photon_pass(0, self.M, first=i * self.M)
+        else:
+            self._photon_pass_allgather(i)
+        return None
+
+    def finish(self):
+        import torch.distributed as dist
+        if self.world > 1:
+            state = self.ctx.export_owned_state()
+            dist.all_reduce(state, op=dist.ReduceOp.SUM)
+            self.ctx.import_state(state)
+        self.image = self.ctx.resolve(0, self.M * self.steps)
+        return self.image
+
+    def gather_image(self):
+        return self.finish()
 
 
 def select_by_owner(stacked, owner):

@@ -151,10 +151,22 @@ class SppmContext:
         capi.check(self.L.sppm_append_records(self.h, rows.data_ptr(), n, photon_first, photon_end))
 
     def owned_mask(self):
-        """uint8 tensor [P] on this device: 1 where this rank owns the pixel's hitpoint."""
-        m = self.torch.empty((self.P,), dtype=self.torch.uint8, device=self.device)
+        """uint8 tensor [hitpoints] on this device: 1 where this rank owns the hitpoint (for sppm2.h: the pixel's)."""
+        m = self.torch.empty((self.n_hitpoints,), dtype=self.torch.uint8, device=self.device)
         capi.check(self.L.sppm_owned_mask(self.h, m.data_ptr()))
         return m
+
+    def export_owned_state(self):
+        """float64 tensor [hitpoints][5]: (r^2, flux, N) where this rank owns the hitpoint, zeros elsewhere."""
+        t = self.torch.empty((self.n_hitpoints, 5), dtype=self.torch.float64, device=self.device)
+        capi.check(self.L.sppm_export_owned_state(self.h, t.data_ptr()))
+        return t
+
+    def import_state(self, state):
+        state = state.to(device=self.device, dtype=self.torch.float64).contiguous()
+        assert tuple(state.shape) == (self.n_hitpoints, 5)
+        capi.check(self.L.sppm_import_state(self.h, state.data_ptr()))
+        self._keep = state  # the copy is asynchronous
 
     # ---- taps ------------------------------------------------------------------------------------
     def hitpoint_pixels(self):

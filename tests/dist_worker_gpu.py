@@ -16,8 +16,20 @@ def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from raytracer_amd.parallel import ShardedSppm
+    from raytracer_amd.parallel import ShardedPpm, ShardedSppm
     W, H, M_rank, passes = 96, 64, 24000, 3
+    if exchange == "ppm":  # classic PPM: one run of `passes` batches; after finish() every rank holds the whole state
+        job = ShardedPpm(W, H, M_rank, passes, rank=rank, world=world, supersamples=2)
+        for i in range(passes):
+            job.step(i)
+        mask = job.ctx.owned_mask().cpu().numpy()
+        img = job.finish().cpu().numpy()
+        job.ctx.check()
+        hp = job.ctx.hitpoints()
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), image=img, n=hp["n"], r2=hp["r2"], flux=hp["flux"], mask=mask)
+        job.close()
+        dist.destroy_process_group()
+        return
     job = ShardedSppm(W, H, photons_per_rank=M_rank, rank=rank, world=world, exchange=exchange, ownership=ownership)
     job.total_passes = passes
     for i in range(passes):

@@ -212,3 +212,44 @@ def test_classic_ppm_full_size_invariants():
     for k in ("n", "r2", "flux"):
         _same(outs[1][0][k], s[k], f"run-to-run {k}")
     _same(outs[1][1], img, "run-to-run image")
+
+
+def test_classic_ppm_three_ranks_equal_one_context():
+    """The hitpoint list shared out over three 'ranks' (contexts on one GPU) by ranges of its Morton order, records
+    exchanged by hand (pack / append), owned state summed: equal to one context that did everything, bit for bit."""
+    import torch
+    W, H, M, N = 64, 48, 30000, 3
+    kw = dict(supersamples=2, photons_per_pass=M, gather_radius2=5.0, initial_radius2=5.0, algorithm=1)
+    full = sppm.SppmContext(sppm.make_config(W, H, **kw))
+    ranks = [sppm.SppmContext(sppm.make_config(W, H, tile_first=r, tile_stride=N, ownership=1, **kw)) for r in range(N)]
+    rows = [torch.empty((8 * M, 10), dtype=torch.float64, device="cuda") for _ in range(N)]
+    full.eye_pass(0)
+    full.photon_pass(0, M)
+    for c in ranks:
+        c.eye_pass(0)
+    for lo in range(0, M, M // 2):        # two batches
+        shard = M // 2 // N
+        cnt = []
+        for r, c in enumerate(ranks):
+            c.trace(0, lo + r * shard, shard)
+            cnt.append(c.pack_records(rows[r]))
+        for c in ranks:
+            for r in range(N):
+                c.append_records(rows[r], cnt[r], lo + r * shard, lo + (r + 1) * shard)
+            c.gather()
+    masks = [c.owned_mask().cpu().numpy().astype(bool) for c in ranks]
+    assert (np.sum(masks, axis=0) == 1).all() and len(masks[0]) == full.n_hitpoints
+    state = sum(c.export_owned_state() for c in ranks)
+    ref = full.hitpoints()
+    st = state.cpu().numpy()
+    _same(st[:, 0], ref["r2"], "r2 summed over ranks")
+    _same(st[:, 1:4], ref["flux"], "flux summed over ranks")
+    _same(st[:, 4].astype(np.int32), ref["n"], "N summed over ranks")
+    ref_img = full.resolve(0, M).cpu().numpy()
+    for c in ranks:
+        c.import_state(state)
+        _same(c.resolve(0, M).cpu().numpy(), ref_img, "image on a rank")
+        c.check()
+    full.check()
+    for c in [full] + ranks:
+        c.close()

@@ -51,3 +51,32 @@ def test_two_ranks_equal_one_gpu(tmp_path, exchange, ownership):
             merged[m] = g[k][m]
         a, b = np.ascontiguousarray(merged), np.ascontiguousarray(ref[k])
         assert (a.view(np.uint64) == b.view(np.uint64)).all() if a.dtype.kind == "f" else (a == b).all(), k
+
+
+def test_two_ranks_classic_ppm_equal_one_gpu(tmp_path):
+    """ShardedPpm: the hitpoint list shared out by ranges of its Morton order, photon records by all-gather, the owned
+    state summed over the ranks at the end: state and image on every rank equal a single-GPU render, bit for bit."""
+    world, W, H, M_rank, steps = 2, 96, 64, 24000, 3
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = 29700 + os.getpid() % 1000
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker_gpu.py"), str(tmp_path), "ppm", "1"]
+    try:
+        res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=100)
+    except subprocess.TimeoutExpired:
+        pytest.skip("the gloo transport did not finish within 100 s")
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    total = M_rank * world * steps
+    ctx = sppm.SppmContext(sppm.make_config(W, H, supersamples=2, photons_per_pass=total, gather_radius2=5.0, initial_radius2=5.0, algorithm=1))
+    ctx.eye_pass(0)
+    ctx.photon_pass(0, total)
+    ref_img, ref = ctx.resolve(0, total).cpu().numpy(), ctx.hitpoints()
+    ctx.check(); ctx.close()
+    got = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    masks = [g["mask"].astype(bool) for g in got]
+    assert (np.sum(masks, axis=0) == 1).all() and abs(int(masks[0].sum()) - int(masks[1].sum())) <= 1
+    for g in got:
+        assert (g["image"].view(np.uint64) == ref_img.view(np.uint64)).all(), "image on a rank differs from the single-GPU image"
+        for k in ("n", "r2", "flux"):
+            a, b = np.ascontiguousarray(g[k]), np.ascontiguousarray(ref[k])
+            assert (a.view(np.uint64) == b.view(np.uint64)).all() if a.dtype.kind == "f" else (a == b).all(), k
