@@ -80,7 +80,7 @@ static std::vector<unsigned char> slurp(const std::string& path)
 int main(int argc, char** argv)
 {
     if (argc < 7) {
-        fprintf(stderr, "usage: %s outdir photons passes traced_photons gather_r2 gather_k [seed_eye seed_photon aperture focus_dist seed_lens]\n", argv[0]);
+        fprintf(stderr, "usage: %s outdir photons passes traced_photons gather_r2 gather_k [seed_eye seed_photon aperture focus_dist seed_lens samples supersamples]\n", argv[0]);
         return 2;
     }
     g_out = argv[1];
@@ -98,7 +98,7 @@ int main(int argc, char** argv)
     const double focus_dist = argc > 10 ? atof(argv[10]) : 180.0;
     const unsigned seed_lens = argc > 11 ? (unsigned)strtoul(argv[11], 0, 10) : 3000u;
     const int W = REF_W, H = REF_H, P = W * H;
-    const int samples = 1, supersamples = 1;
+    const int samples = argc > 12 ? atoi(argv[12]) : 1, supersamples = argc > 13 ? atoi(argv[13]) : 1;
 
     std::streambuf* cout_buf = std::cout.rdbuf();
     std::ofstream devnull("/dev/null");

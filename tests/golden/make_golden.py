@@ -25,16 +25,20 @@ def rd(d, name, dt):
     return np.fromfile(os.path.join(d, name), dtype=dt)
 
 
-def run(tag, w, h, photons, passes, traced, r2, k, seed_eye, seed_photon, full, dof=None):
+def run(tag, w, h, photons, passes, traced, r2, k, seed_eye, seed_photon, full, dof=None, spp=None):
     exe = os.path.join(ORACLE, "_ref", f"ref_driver_{w}x{h}")
     with tempfile.TemporaryDirectory() as d:
         cmd = [exe, d, str(photons), str(passes), str(traced), repr(float(r2)), str(k), str(seed_eye), str(seed_photon)]
-        if dof:  # thin-lens camera: aperture, focus distance, seed of the lens engine
-            cmd += [repr(float(dof[0])), repr(float(dof[1])), str(dof[2])]
+        if dof or spp:  # thin-lens camera: aperture (0 = pinhole), focus distance, seed of the lens engine
+            cmd += [repr(float(dof[0])), repr(float(dof[1])), str(dof[2])] if dof else ["0", "180", "3000"]
+        if spp:  # samples, supersamples
+            cmd += [str(spp[0]), str(spp[1])]
         subprocess.check_call(cmd)
         P = w * h
         out = dict(meta=np.array([w, h, photons, passes, traced, k, seed_eye, seed_photon], np.int64),
                    gather_r2=np.array([r2], np.float64))
+        if spp:
+            out["spp"] = np.array(spp, np.int64)
         if dof:
             out["dof"] = np.array(dof, np.float64)
             out["dof_rays"] = rd(d, "dof_rays.bin", np.float64).reshape(P, 6)
@@ -123,6 +127,8 @@ def main():
     run("320x240", 320, 240, 200000, 2, 1024, 25.0, 100000, 1000, 2000, False)
     # eye rays through DoFCamera::get_ray (aperture 4, focus 180 as in the commented-out member of src/sppm2.h:73-79)
     run("64x48_dof", 64, 48, 20000, 2, 1024, 25.0, 100000, 1000, 2000, False, dof=(4.0, 180.0, 3000))
+    # several eye paths per pixel: samples = 2, supersamples = 2 (the last path's hitpoint stays, the direct terms add up)
+    run("64x48_spp", 64, 48, 20000, 2, 1024, 25.0, 100000, 1000, 2000, False, spp=(2, 2))
     # tag, W, H, photons, per-photon-traced, search r^2 (= InitialRadius, main.cpp:76-77), K cap, seeds, supersamples
     run_ppm("64x48", 64, 48, 20000, 4096, 25.0, 100000, 1000, 2000, 1)
     run_ppm("48x36_ss2_r5", 48, 36, 30000, 2048, 5.0, 100000, 31, 77, 2)

@@ -358,3 +358,24 @@ def test_k_cap_check_counts_every_querys_candidates():
             with pytest.raises(capi.SppmError, match="gather_max"):
                 ctx.check()
         ctx.close()
+
+
+def test_several_eye_paths_per_pixel_match_oracle():
+    """samples = 2, supersamples = 2 (the loops of src/sppm2.h:628-643): the last path's hitpoint stays, the direct
+    terms of all paths add up."""
+    W, H, M = 48, 36, 15000
+    ctx, orc = _pair(W, H, M, samples=2, supersamples=2)
+    for i in range(2):
+        ctx.eye_pass(i)
+        orc.eye_pass(i)
+        s, o = ctx.hitpoints(), orc.state()
+        for k in ("valid", "obj", "hp_f", "ld"):
+            _same(s[k], o[k], f"pass {i} eye {k}")
+        ctx.photon_pass(i, M)
+        orc.photon_pass(i, M)
+        s, o = ctx.hitpoints(), orc.state()
+        for k in ("n", "r2", "flux"):
+            _same(s[k], o[k], f"pass {i} state {k}")
+        _same(ctx.resolve(i, M).cpu().numpy(), orc.resolve(i, M), f"pass {i} image")
+    ctx.check()
+    ctx.close()

@@ -20,13 +20,14 @@ def _rel_rmse(a, b):
     return float(np.sqrt(np.mean((a - b) ** 2)) / np.sqrt(np.mean(b ** 2)))
 
 
-@pytest.mark.parametrize("tag", ["64x48", "64x48_r5", "320x240"])
+@pytest.mark.parametrize("tag", ["64x48", "64x48_r5", "320x240", "64x48_spp"])
 def test_gpu_renders_the_reference_image(golden, tag, tmp_path):
     g = golden(tag)
     w, h, photons, passes, traced, k, se, sp = [int(x) for x in g["meta"]]
     st = int(g["stride"][0])
+    spp = dict(samples=int(g["spp"][0]), supersamples=int(g["spp"][1])) if "spp" in g else {}   # several eye paths per pixel
     cfg = sppm.make_config(w, h, gather_radius2=float(g["gather_r2"][0]), gather_max=k, seed_eye=se, seed_photon=sp,
-                           photons_per_pass=photons, sampler=1)
+                           photons_per_pass=photons, sampler=1, **spp)
     ctx = sppm.SppmContext(cfg)
     img = None
     for i in range(passes):

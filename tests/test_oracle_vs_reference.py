@@ -34,12 +34,14 @@ def test_stateless_pieces(golden):
     _bits(ol.to_int(g["encode_in"]).reshape(-1, 3), g["encode_toint"], "to_int")
 
 
-@pytest.mark.parametrize("tag", ["64x48", "64x48_r5", "320x240", "64x48_dof"])
+@pytest.mark.parametrize("tag", ["64x48", "64x48_r5", "320x240", "64x48_dof", "64x48_spp"])
 def test_sppm_passes(golden, tag):
     g = golden(tag)
     w, h, photons, passes, traced, k, se, sp = [int(x) for x in g["meta"]]
     st = int(g["stride"][0])
     cam = {}
+    if "spp" in g:
+        cam = dict(samples=int(g["spp"][0]), supersamples=int(g["spp"][1]))
     if "dof" in g:  # eye rays through DoFCamera::get_ray (src/cameras.h:123-139), lens draws from their own engine
         cam = dict(camera_model=1, aperture=float(g["dof"][0]), focus_dist=float(g["dof"][1]), seed_lens=int(g["dof"][2]))
         _bits(ol.camera_rays(ol.make_params(w, h, sampler=0, math=0, **cam)), g["dof_rays"], "DoFCamera::get_ray")
