@@ -158,6 +158,24 @@ def main_ppm(args, rank, world, barrier):
         dist.destroy_process_group()
 
 
+def measured_stream_bandwidth(torch, gib=2):
+    """What HBM delivers on THIS box to a plain device-to-device copy (bytes read + bytes written per second), beside the
+    8 TB/s of the data sheet: the second denominator SURVEY 8(d) asks for."""
+    n = gib * (1 << 30) // 8
+    src = torch.ones(n, dtype=torch.float64, device="cuda")
+    dst = torch.empty_like(src)
+    for _ in range(3):
+        dst.copy_(src)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    reps = 20
+    for _ in range(reps):
+        dst.copy_(src)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2.0 * n * 8 * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
 def measured_traffic(width, height, photons, steps):
     """HBM bytes per k_gather_tiles launch from the committed PMC passes (profiles/r01_pmc_traffic.json:
     FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3 --pmc runs of this script, FETCH_SIZE
@@ -299,6 +317,10 @@ def main():
                                  "rays_per_launch": p_rays / t_launch,
                                  "note": "rank 0; 219 flop per ray (20 x 9 spheres + 19, SURVEY 8d) x rays cast by photon tracing; overlapped with the gather"}
         out["roofline"]["traffic"] = measured_traffic(W, H, M, args.steps)
+        bw = measured_stream_bandwidth(torch)
+        out["roofline"]["peak_measured"] = bw
+        out["roofline"]["frac_of_measured"] = achieved / bw
+        out["roofline"]["note"] += "; peak_measured = device-to-device copy of 2 GiB on this box (read + write bytes per second)"
         if args.spheres > 0:
             out["roofline_trace"]["note"] = "rank 0; rays cast by photon tracing; the flop figure prices a ray at the Cornell scene's 219 flop (a grid walk tests fewer spheres per ray than brute force, so this is not a flop count for this scene)"
         if world == 1 and not args.no_cpu_baseline:

@@ -1356,6 +1356,7 @@ static int build_scene_grid(sppm_ctx* c, const sppm_sphere* sp, int n)
     const double vol = std::max(1e-30, (hi[0] - lo[0]) * (hi[1] - lo[1]) * (hi[2] - lo[2]));
     double cell = std::max(std::cbrt(vol / (2.0 * (double)small.size())), 2.0 * sorted[small.size() / 2 < (size_t)n ? small.size() / 2 : 0]);
     if (!(cell > 0.0)) cell = std::max(diag, 1.0);
+    { const char* e = getenv("SPPM_GRID_CELL_FACTOR"); if (e && *e && atof(e) > 0.0) cell *= atof(e); }
     std::vector<uint32_t> start;
     std::vector<int32_t> items;
     int dims[3];
