@@ -63,7 +63,7 @@ struct XorShift {
 // (src/sampler/value_sampler.h:8-15: std::mt19937 + uniform_real_distribution<double>(0,1), shared by
 // every pixel of every eye pass / every photon of a photon pass).  The host generates the stream
 // (std::mt19937, same library code as the reference); a path reads it from the offset where the paths
-// before it stopped.  See "reference-stream mode" in sppm_kernels.hip for how those offsets are found
+// before it stopped.  See "reference-stream mode" in sppm_eye.hpp / sppm_trace.hpp for how those offsets are found
 // in parallel.
 struct StreamRng {
     const double* u; int64_t pos, end;

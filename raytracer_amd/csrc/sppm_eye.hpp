@@ -1,0 +1,438 @@
+// sppm_eye.hpp -- the eye pass: camera rays and first hits, hitpoint arrays, create_point_loop per pixel (sppm2.h), the hitpoint list of classic PPM, and the reference-stream variants.
+// Part of the single translation unit sppm_kernels.hip (included there, in order; not a stand-alone header).
+#pragma once
+
+__global__ void k_camera_rays(Camera cam, int W, int H, int sx, int sy, uint32_t seed_lens, const double* __restrict__ lens_u, double* __restrict__ rays)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= W * H) return;
+    const int x = i % W, y = i / W;
+    d3 o, d;
+    if (cam.model == 1) {  // lens draws: the stream of image index (H-y-1)*W+x at pass 0, or draws 2i, 2i+1 of the sequential stream
+        LensRng l;
+        l.u = lens_u; l.pos = 2ll * i; l.mode = lens_u ? 2 : 1;
+        l.xs = make_stream(seed_lens, (uint64_t)((H - y - 1) * W + x));
+        camera_ray_lens(cam, x, y, sx, sy, l, o, d);
+    } else
+        camera_ray(cam, x, y, sx, sy, o, d);
+    double* r = rays + 6 * (size_t)i;
+    r[0] = o.x; r[1] = o.y; r[2] = o.z; r[3] = d.x; r[4] = d.y; r[5] = d.z;
+}
+
+__global__ void k_intersect(DevScene sc, const double* __restrict__ rays, int64_t n, int32_t* __restrict__ id,
+                            double* __restrict__ out)
+{
+    STAGE_SCENE(sc);
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Hit h;
+    const bool hit = intersect_scene(sc, ld3(rays + 6 * i), ld3(rays + 6 * i + 3), h);
+    id[i] = hit ? h.object_id : -1;
+    double* o = out + 7 * i;
+    o[0] = h.distance;
+    if (hit) { o[1] = h.position.x; o[2] = h.position.y; o[3] = h.position.z; o[4] = h.normal.x; o[5] = h.normal.y; o[6] = h.normal.z; }
+    else { o[1] = o[2] = o[3] = o[4] = o[5] = o[6] = 0.0; }
+}
+
+struct HpArrays {
+    double *pos, *nrm, *w, *flux, *ld, *phi, *tau;  // [3][P]
+    double *r2, *dist, *nd;
+    int32_t *n, *obj, *valid, *madd;
+    int P;
+};
+
+struct EyeParams {
+    Camera cam; int W, H, samples, supersamples; int pass; uint32_t seed_eye; double initial_r2; int double_nee;
+    // reference-stream mode only
+    const double* u; int64_t u_len; uint32_t* cnt; unsigned long long* off; unsigned long long* total;
+    // classic progressive photon mapping only: hitpoints per pixel (out) / first hitpoint slot per pixel (in),
+    // both indexed by the pixel's place t in the render order
+    uint32_t* hcnt; const long long* hoff;
+    // thin-lens camera: seed of the per-(pass, pixel) lens streams; reference-stream mode: this pass's lens draws
+    uint32_t seed_lens; const double* lens_u;
+};
+
+__device__ __forceinline__ LensRng make_lens(const EyeParams& ep, int t, int index)
+{
+    LensRng l;
+    l.u = ep.lens_u; l.pos = 0; l.mode = 0; l.xs.seed(1u);
+    if (ep.cam.model == 1) {
+        if (ep.lens_u) { l.mode = 2; l.pos = 2ll * t * (ep.samples * ep.supersamples * ep.supersamples); }
+        else { l.mode = 1; l.xs = make_stream(ep.seed_lens, (uint64_t)ep.pass * (uint64_t)(ep.W * ep.H) + (uint64_t)index); }
+    }
+    return l;
+}
+
+// One pixel of an eye pass: the sy/sx/s loops of src/sppm2.h:628-643 around create_point_loop
+// (:156-315).  t = y*W + x is the pixel's place in the reference's render order.  COMMIT = false runs
+// the same paths without storing anything (used to count draws).
+template <class RNG, bool COMMIT, int GRID = SCENE_ANY>
+__device__ __forceinline__ void eye_pixel(const DevScene& sc, const EyeParams& ep, const HpArrays& hp, const HpArrays& out, int t, RNG& rng, uint32_t& rays)
+{
+    const int P = ep.W * ep.H;
+    const int x = t % ep.W, y = t / ep.W;
+    const int index = (ep.H - y - 1) * ep.W + x;
+    d3 ld = mk(hp.ld[index], hp.ld[P + index], hp.ld[2 * P + index]);
+    int valid = hp.valid[index];
+    bool wrote = false;  // a hitpoint was stored for this pixel in this pass
+    LensRng lens = make_lens(ep, t, index);
+    for (int sy = 0; sy < ep.supersamples; sy++)
+        for (int sx = 0; sx < ep.supersamples; sx++)
+            for (int s = 0; s < ep.samples; s++) {
+                d3 org, dir;
+                if (ep.cam.model == 1) camera_ray_lens(ep.cam, x, y, sx, sy, lens, org, dir);
+                else camera_ray(ep.cam, x, y, sx, sy, org, dir);
+                int depth = -1;
+                bool direct = true;
+                d3 weight = mk(1, 1, 1);
+                for (;;) {
+                    depth++;
+                    Hit is;
+                    rays++;
+                    if (!intersect_scene<GRID>(sc, org, dir, is)) break;
+                    const sppm_sphere* obj = &sc.sp[is.object_id];
+                    const d3 color = ld3(obj->color);
+                    const int type = obj->reflection_type;
+                    const d3 on = dot(is.normal, dir) < 0.0 ? is.normal : is.normal * -1.0;
+                    if (direct) ld = ld + had(weight, ld3(obj->emission));
+                    direct = type != SPPM_DIFFUSE;
+                    if (type == SPPM_DIFFUSE) {
+                        const d3 est = next_event_est<RNG, GRID>(sc, is, on, rng, rays);
+                        ld = ld + had(weight, est);
+                        // create or overwrite the pixel's hitpoint (src/sppm2.h:204-227)
+                        if constexpr (COMMIT) {
+                            out.pos[index] = is.position.x; out.pos[P + index] = is.position.y; out.pos[2 * P + index] = is.position.z;
+                            out.nrm[index] = is.normal.x; out.nrm[P + index] = is.normal.y; out.nrm[2 * P + index] = is.normal.z;
+                            out.w[index] = weight.x; out.w[P + index] = weight.y; out.w[2 * P + index] = weight.z;
+                            out.obj[index] = is.object_id; out.dist[index] = is.distance;
+                            wrote = true;
+                        }
+                        if (!valid) {
+                            valid = 1;
+                            if constexpr (COMMIT) {
+                                hp.r2[index] = ep.initial_r2;
+                                hp.n[index] = 0;  // the reference leaves photon_count unset (src/sppm2.h:108-116); its call site passes 0
+                                hp.flux[index] = 0.0; hp.flux[P + index] = 0.0; hp.flux[2 * P + index] = 0.0;
+                                if (hp.nd) {
+                                    hp.nd[index] = 0.0; hp.madd[index] = 0;
+                                    hp.phi[index] = 0.0; hp.phi[P + index] = 0.0; hp.phi[2 * P + index] = 0.0;
+                                    hp.tau[index] = 0.0; hp.tau[P + index] = 0.0; hp.tau[2 * P + index] = 0.0;
+                                }
+                            }
+                            // the reference's `break` leaves the switch only: fall into the roulette
+                            // block and go round again with the same ray (second direct sample)
+                            if (!ep.double_nee) goto path_done;
+                        } else
+                            goto path_done;
+                    } else if (type == SPPM_SPECULAR) {
+                        org = is.position;
+                        dir = reflect_dir(dir, is.normal);
+                        weight = had(weight, color);
+                    } else {
+                        const d3 rdir = reflect_dir(dir, is.normal);
+                        bool into; double nnt, Re; d3 tdir;
+                        org = is.position;
+                        if (!glass(dir, is.normal, on, true, into, nnt, tdir, Re)) {
+                            dir = rdir;
+                            weight = had(weight, color);
+                        } else {
+                            const double nnt2 = nnt * nnt;
+                            const double Tr = (1.0 - Re) * nnt2;
+                            const double prob = 0.25 + 0.5 * Re;
+                            rng.decision();
+                            if (rng.next01() < prob) {
+                                dir = rdir;
+                                weight = had(weight, color * Re / prob);
+                            } else {
+                                dir = tdir;
+                                weight = had(weight, color * Tr / (1.0 - prob));
+                            }
+                        }
+                    }
+                    {   // Russian roulette, src/sppm2.h:298-313
+                        double rr = max3(color);
+                        if (depth >= SPPM_KDEPTH) {
+                            rr *= ldexp(1.0, -(depth - SPPM_KDEPTH));  // std::pow(0.5, depth - MaxDepth)
+                            rng.decision();
+                            if (rng.next01() >= rr) break;
+                        } else
+                            rr = 1.0;
+                        weight = weight / rr;
+                    }
+                    if (rng.stop()) return;  // sequential-stream samplers only
+                }
+            path_done:;
+            }
+    if constexpr (COMMIT) {
+        // `out` is the view the NEXT gather reads (the eye pass of pass i+1 may run while the gather of pass i
+        // still reads `hp`): the direct term, the valid flag, and -- where this pass stored no hitpoint -- the
+        // hitpoint the pixel already had (the reference overwrites a pixel's hitpoint only on a diffuse hit)
+        out.ld[index] = ld.x; out.ld[P + index] = ld.y; out.ld[2 * P + index] = ld.z;
+        out.valid[index] = valid;
+        if (!wrote && valid) {
+            out.pos[index] = hp.pos[index]; out.pos[P + index] = hp.pos[P + index]; out.pos[2 * P + index] = hp.pos[2 * P + index];
+            out.nrm[index] = hp.nrm[index]; out.nrm[P + index] = hp.nrm[P + index]; out.nrm[2 * P + index] = hp.nrm[2 * P + index];
+            out.w[index] = hp.w[index]; out.w[P + index] = hp.w[P + index]; out.w[2 * P + index] = hp.w[2 * P + index];
+            out.obj[index] = hp.obj[index]; out.dist[index] = hp.dist[index];
+        }
+    }
+}
+
+// One thread per pixel, one XorShift stream per (pass, image index).
+template <int GRID>
+__global__ void __launch_bounds__(256) k_eye_pass(DevScene sc, EyeParams ep, HpArrays hp, HpArrays out, unsigned long long* __restrict__ counters)
+{
+    STAGE_SCENE_T(sc, GRID);
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int P = ep.W * ep.H;
+    uint32_t rays = 0;
+    if (t < P) {
+        const int index = (ep.H - t / ep.W - 1) * ep.W + t % ep.W;
+        XorShift rng = make_stream(ep.seed_eye, (uint64_t)ep.pass * (uint64_t)P + (uint64_t)index);
+        eye_pixel<XorShift, true, GRID>(sc, ep, hp, out, t, rng, rays);
+    }
+    // rays counter: one atomic per wave
+    for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off);
+    if ((threadIdx.x & 63) == 0 && rays) atomicAdd(&counters[0], (unsigned long long)rays);
+}
+
+// ---- classic progressive photon mapping: the eye pass ------------------------------------------------------
+// create_point, src/progressive_photonmapping.h:496-615, for one pixel: the sy/sx/s loops of render()
+// (:769-791) around a recursion that leaves a hitpoint at EVERY diffuse surface it reaches.  Glass follows
+// both branches while depth <= 2 (reflection first, :606-609) and one branch chosen by a draw afterwards
+// (:586-603); roulette from depth > kDepth (:519-524); the weight is a scalar.  The recursion is a loop with
+// a stack: only the refracted branches of depths 0, 1 and 2 can be pending at the same time, and the draws
+// are consumed in the reference's depth-first order.  Hitpoints go to slots base, base+1, ... in creation
+// order (COMMIT); the function returns how many the pixel has.
+#define PPM_DEPTH_LIMIT 64  // kDepthLimit, src/radiance.h:18
+template <class RNG, bool COMMIT>
+__device__ __forceinline__ int ppm_pixel(const DevScene& sc, const EyeParams& ep, const HpArrays& out, int t, long long base, RNG& rng, uint32_t& rays)
+{
+    const int P = out.P;
+    const int x = t % ep.W, y = t / ep.W;
+    int count = 0;
+    for (int sy = 0; sy < ep.supersamples; sy++)
+        for (int sx = 0; sx < ep.supersamples; sx++)
+            for (int s = 0; s < ep.samples; s++) {
+                d3 org, dir;
+                camera_ray(ep.cam, x, y, sx, sy, org, dir);
+                double weight = 1.0;
+                int depth = 0;
+                d3 st_org[3], st_dir[3]; double st_w[3]; int st_depth[3];
+                int sp = 0;
+                for (;;) {  // one create_point call per trip
+                    bool ended = true;
+                    Hit is;
+                    rays++;
+                    if (intersect_scene(sc, org, dir, is)) {
+                        const sppm_sphere* obj = &sc.sp[is.object_id];
+                        const d3 color = ld3(obj->color);
+                        const int type = obj->reflection_type;
+                        const d3 on = dot(is.normal, dir) < 0.0 ? is.normal : is.normal * -1.0;
+                        double rr = max3(color);
+                        if (depth > PPM_DEPTH_LIMIT) rr *= ldexp(1.0, -(depth - PPM_DEPTH_LIMIT));  // std::pow(0.5, depth - kDepthLimit)
+                        bool alive = true;
+                        if (depth > SPPM_KDEPTH) {
+                            rng.decision();
+                            if (rng.next01() >= rr) alive = false;
+                        } else
+                            rr = 1.0;
+                        if (alive) {
+                            if (type == SPPM_DIFFUSE) {  // :529-534
+                                if constexpr (COMMIT) {
+                                    const long long h = base + count;
+                                    const double w = weight / rr;
+                                    out.pos[h] = is.position.x; out.pos[P + h] = is.position.y; out.pos[2 * (long long)P + h] = is.position.z;
+                                    out.nrm[h] = is.normal.x; out.nrm[P + h] = is.normal.y; out.nrm[2 * (long long)P + h] = is.normal.z;
+                                    out.w[h] = w; out.w[P + h] = w; out.w[2 * (long long)P + h] = w;
+                                    out.obj[h] = is.object_id; out.dist[h] = is.distance; out.valid[h] = 1;
+                                    out.r2[h] = ep.initial_r2;
+                                    out.n[h] = 0;  // the constructor drops photon_count (:46-55); its call site passes 0
+                                    out.flux[h] = 0.0; out.flux[P + h] = 0.0; out.flux[2 * (long long)P + h] = 0.0;
+                                }
+                                count++;
+                            } else if (type == SPPM_SPECULAR) {  // :537-544
+                                org = is.position;
+                                dir = reflect_dir(dir, is.normal);
+                                weight = weight / rr;
+                                depth++;
+                                ended = false;
+                            } else {
+                                const d3 rdir = reflect_dir(dir, is.normal);
+                                bool into; double nnt, Re; d3 tdir;
+                                org = is.position;
+                                if (!glass(dir, is.normal, on, false, into, nnt, tdir, Re)) {  // :561-566
+                                    dir = rdir;
+                                    weight = weight / rr;
+                                } else {
+                                    const double nnt2 = nnt * nnt;  // std::pow(nnt, 2.0)
+                                    const double Tr = (1.0 - Re) * nnt2;
+                                    const double prob = 0.25 + 0.5 * Re;
+                                    if (depth > 2) {
+                                        rng.decision();
+                                        if (rng.next01() < prob) { dir = rdir; weight = weight * Re / (prob * rr); }
+                                        else { dir = tdir; weight = weight * Tr / ((1.0 - prob) * rr); }
+                                    } else {  // both: the reflected branch now, the refracted one once that subtree is done
+                                        st_org[sp] = org; st_dir[sp] = tdir; st_w[sp] = weight * Tr / rr; st_depth[sp] = depth + 1;
+                                        sp++;
+                                        dir = rdir;
+                                        weight = weight * Re / rr;
+                                    }
+                                }
+                                depth++;
+                                ended = false;
+                            }
+                        }
+                    }
+                    if (rng.stop()) return count;  // sequential-stream samplers only
+                    if (ended) {
+                        if (sp == 0) break;
+                        sp--;
+                        org = st_org[sp]; dir = st_dir[sp]; weight = st_w[sp]; depth = st_depth[sp];
+                    }
+                }
+            }
+    return count;
+}
+
+// One thread per pixel (t = place in the render order), one XorShift stream per image index.  COMMIT = false
+// counts the pixel's hitpoints (hcnt[t]); COMMIT = true stores them from slot hoff[t] on.
+template <bool COMMIT>
+__global__ void __launch_bounds__(256) k_ppm_eye(DevScene sc, EyeParams ep, HpArrays out, unsigned long long* __restrict__ counters, int32_t* __restrict__ err)
+{
+    STAGE_SCENE(sc);
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int npix = ep.W * ep.H;
+    uint32_t rays = 0;
+    if (t < npix) {
+        const int index = (ep.H - t / ep.W - 1) * ep.W + t % ep.W;
+        XorShift rng = make_stream(ep.seed_eye, (uint64_t)index);
+        const int n = ppm_pixel<XorShift, COMMIT>(sc, ep, out, t, COMMIT ? ep.hoff[t] : 0ll, rng, rays);
+        if constexpr (COMMIT) { if ((long long)n != ep.hoff[t + 1] - ep.hoff[t]) err[5] = 1; }
+        else ep.hcnt[t] = (uint32_t)n;
+    }
+    if constexpr (COMMIT) {
+        for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off);
+        if ((threadIdx.x & 63) == 0 && rays) atomicAdd(&counters[0], (unsigned long long)rays);
+    }
+}
+
+// image assembly of render(), src/progressive_photonmapping.h:807-813: one thread per pixel sums its
+// hitpoints in creation order (the reference walks its kd-sorted vector; the two orders differ by the
+// rounding of a sum of a few terms).
+__global__ void k_ppm_resolve(HpArrays hp, DevScene sc, const long long* __restrict__ hoff, int W, int H, int64_t photon_num, double spp, double* __restrict__ image)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= W * H) return;
+    const int index = (H - t / W - 1) * W + t % W;
+    const long long P = hp.P;
+    d3 c = mk(0, 0, 0);
+    for (long long h = hoff[t]; h < hoff[t + 1]; h++) {
+        const d3 em = ld3(sc.sp[hp.obj[h]].emission);
+        const d3 flux = mk(hp.flux[h], hp.flux[P + h], hp.flux[2 * P + h]);
+        c = c + (em + flux * hp.w[h] * (1.0 / (SPPM_PI * hp.r2[h] * (double)photon_num))) / spp;
+    }
+    image[3 * (size_t)index] = c.x; image[3 * (size_t)index + 1] = c.y; image[3 * (size_t)index + 2] = c.z;
+}
+
+// ---- reference-stream mode of the eye pass ----------------------------------------------------------
+// The reference draws every pixel's samples from ONE sequential stream (src/sppm2.h:621), so pixel t
+// starts where pixels 0..t-1 stopped.  Most pixels consume a number of draws that does not depend on
+// the values drawn (a diffuse first hit: the light samples only); the rest (a glass vertex, roulette
+// from depth 5 on) are "dynamic".  Three kernels: count/classify in parallel, one wavefront walks the
+// pixels in render order and resolves the dynamic ones with the real stream, then the pass itself runs
+// in parallel from the offsets found.  DYN_PIXEL marks a dynamic pixel in cnt[].
+#define DYN_PIXEL 0x80000000u
+template <int ALGO>  // 0: sppm2.h, 1: progressive_photonmapping.h
+__global__ void __launch_bounds__(256) k_eye_classify(DevScene sc, EyeParams ep, HpArrays hp)
+{
+    STAGE_SCENE(sc);
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ep.W * ep.H) return;
+    ProbeRng rng;
+    rng.count = 0; rng.dyn = false;
+    uint32_t rays = 0;
+    if constexpr (ALGO == 0) eye_pixel<ProbeRng, false>(sc, ep, hp, hp, t, rng, rays);
+    else (void)ppm_pixel<ProbeRng, false>(sc, ep, hp, t, 0ll, rng, rays);
+    ep.cnt[t] = rng.dyn ? DYN_PIXEL : (uint32_t)rng.count;
+}
+
+template <int ALGO>
+__global__ void __launch_bounds__(64) k_eye_offsets(DevScene sc, EyeParams ep, HpArrays hp, int32_t* __restrict__ err)
+{
+    STAGE_SCENE(sc);
+    const int lane = threadIdx.x;
+    const int P = ep.W * ep.H;
+    unsigned long long cur = 0;
+    for (int base = 0; base < P; base += 64) {
+        const int t = base + lane;
+        const uint32_t c = t < P ? ep.cnt[t] : 0u;
+        const unsigned long long dyn = __ballot(t < P && (c & DYN_PIXEL) != 0u);
+        int pos = 0;
+        while (pos < 64) {
+            const unsigned long long rest = dyn & (pos == 0 ? ~0ull : (~0ull << pos));
+            const int f = rest ? __ffsll((long long)rest) - 1 : 64;
+            // lanes [pos, f): offsets from a prefix sum of their fixed counts
+            const bool in = lane >= pos && lane < f;
+            unsigned long long incl = in ? (unsigned long long)c : 0ull;
+            for (int o = 1; o < 64; o <<= 1) { const unsigned long long y = __shfl_up(incl, o); if (lane >= o) incl += y; }
+            if (in && t < P) ep.off[t] = cur + incl - c;
+            cur += __shfl(incl, 63);
+            if (f < 64) {  // the dynamic pixel: run its paths on the real stream to see where it stops
+                unsigned long long used = 0;
+                if (lane == f) {
+                    ep.off[t] = cur;
+                    StreamRng rng; rng.u = ep.u; rng.pos = (int64_t)cur; rng.end = ep.u_len;
+                    uint32_t rays = 0;
+                    if constexpr (ALGO == 0) eye_pixel<StreamRng, false>(sc, ep, hp, hp, t, rng, rays);
+                    else (void)ppm_pixel<StreamRng, false>(sc, ep, hp, t, 0ll, rng, rays);
+                    used = (unsigned long long)rng.pos - cur;
+                    if (rng.stop()) err[4] = 1;
+                }
+                cur += __shfl(used, f);
+            }
+            pos = f + 1;
+        }
+    }
+    if (lane == 0) { ep.total[0] = cur; if ((int64_t)cur > ep.u_len) err[4] = 1; }
+}
+
+__global__ void __launch_bounds__(256) k_eye_pass_stream(DevScene sc, EyeParams ep, HpArrays hp, HpArrays out, unsigned long long* __restrict__ counters,
+                                                        int32_t* __restrict__ err)
+{
+    STAGE_SCENE(sc);
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int P = ep.W * ep.H;
+    uint32_t rays = 0;
+    if (t < P) {
+        StreamRng rng; rng.u = ep.u; rng.pos = (int64_t)ep.off[t]; rng.end = ep.u_len;
+        eye_pixel<StreamRng, true>(sc, ep, hp, out, t, rng, rays);
+        // the pixel must stop exactly where the walk said the next one starts
+        const unsigned long long next = t + 1 < P ? ep.off[t + 1] : ep.total[0];
+        if ((unsigned long long)rng.pos != next) err[5] = 1;
+    }
+    for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off);
+    if ((threadIdx.x & 63) == 0 && rays) atomicAdd(&counters[0], (unsigned long long)rays);
+}
+
+// classic PPM on the reference's stream: pixel t reads from off[t]; COMMIT as in k_ppm_eye
+template <bool COMMIT>
+__global__ void __launch_bounds__(256) k_ppm_eye_stream(DevScene sc, EyeParams ep, HpArrays out, unsigned long long* __restrict__ counters, int32_t* __restrict__ err)
+{
+    STAGE_SCENE(sc);
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int npix = ep.W * ep.H;
+    uint32_t rays = 0;
+    if (t < npix) {
+        StreamRng rng; rng.u = ep.u; rng.pos = (int64_t)ep.off[t]; rng.end = ep.u_len;
+        const int n = ppm_pixel<StreamRng, COMMIT>(sc, ep, out, t, COMMIT ? ep.hoff[t] : 0ll, rng, rays);
+        const unsigned long long next = t + 1 < npix ? ep.off[t + 1] : ep.total[0];
+        if ((unsigned long long)rng.pos != next) err[5] = 1;
+        if constexpr (COMMIT) { if ((long long)n != ep.hoff[t + 1] - ep.hoff[t]) err[5] = 1; }
+        else ep.hcnt[t] = (uint32_t)n;
+    }
+    if constexpr (COMMIT) {
+        for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off);
+        if ((threadIdx.x & 63) == 0 && rays) atomicAdd(&counters[0], (unsigned long long)rays);
+    }
+}

@@ -140,7 +140,7 @@ __global__ void k_hp_sortkeys(HpArrays hp, const int32_t* __restrict__ pix, int 
 }
 
 // (slab, cell) bucket of every record of the batch
-// nm.cells != nullptr: records that cannot matter to this rank (near_rank, sppm_kernels.hip) are dropped here.  Only
+// nm.cells != nullptr: records that cannot matter to this rank (near_rank, sppm_exchange.hpp) are dropped here.  Only
 // used when the occupancy map is known to be current (binning on the context's stream).
 __global__ void k_bin_count(RecArrays rec, const unsigned long long* __restrict__ rec_count, TileGrid g, uint32_t* __restrict__ cell_cnt,
                             uint32_t* __restrict__ rec_bucket, int32_t* __restrict__ err, NearMap nm)

@@ -1,4 +1,5 @@
-// sppm_kernels.hip -- gfx950 kernels and the C ABI (include/sppm_hip.h) of the SPPM path.
+// sppm_kernels.hip -- the translation unit of libsppm_hip.so: the gfx950 kernels (included below, one header per
+// stage) and the host side / C ABI (include/sppm_hip.h) of the SPPM path.
 //
 // Data layout in HBM (P = pixels = hitpoint slots, R = photon-hit records of one batch):
 //   hitpoints, SoA by component, indexed by image index:
@@ -33,1155 +34,12 @@
 
 // ================================ kernels ==========================================================
 
-
-__global__ void k_camera_rays(Camera cam, int W, int H, int sx, int sy, uint32_t seed_lens, const double* __restrict__ lens_u, double* __restrict__ rays)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= W * H) return;
-    const int x = i % W, y = i / W;
-    d3 o, d;
-    if (cam.model == 1) {  // lens draws: the stream of image index (H-y-1)*W+x at pass 0, or draws 2i, 2i+1 of the sequential stream
-        LensRng l;
-        l.u = lens_u; l.pos = 2ll * i; l.mode = lens_u ? 2 : 1;
-        l.xs = make_stream(seed_lens, (uint64_t)((H - y - 1) * W + x));
-        camera_ray_lens(cam, x, y, sx, sy, l, o, d);
-    } else
-        camera_ray(cam, x, y, sx, sy, o, d);
-    double* r = rays + 6 * (size_t)i;
-    r[0] = o.x; r[1] = o.y; r[2] = o.z; r[3] = d.x; r[4] = d.y; r[5] = d.z;
-}
-
-__global__ void k_intersect(DevScene sc, const double* __restrict__ rays, int64_t n, int32_t* __restrict__ id,
-                            double* __restrict__ out)
-{
-    STAGE_SCENE(sc);
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    Hit h;
-    const bool hit = intersect_scene(sc, ld3(rays + 6 * i), ld3(rays + 6 * i + 3), h);
-    id[i] = hit ? h.object_id : -1;
-    double* o = out + 7 * i;
-    o[0] = h.distance;
-    if (hit) { o[1] = h.position.x; o[2] = h.position.y; o[3] = h.position.z; o[4] = h.normal.x; o[5] = h.normal.y; o[6] = h.normal.z; }
-    else { o[1] = o[2] = o[3] = o[4] = o[5] = o[6] = 0.0; }
-}
-
-struct HpArrays {
-    double *pos, *nrm, *w, *flux, *ld, *phi, *tau;  // [3][P]
-    double *r2, *dist, *nd;
-    int32_t *n, *obj, *valid, *madd;
-    int P;
-};
-
-struct EyeParams {
-    Camera cam; int W, H, samples, supersamples; int pass; uint32_t seed_eye; double initial_r2; int double_nee;
-    // reference-stream mode only
-    const double* u; int64_t u_len; uint32_t* cnt; unsigned long long* off; unsigned long long* total;
-    // classic progressive photon mapping only: hitpoints per pixel (out) / first hitpoint slot per pixel (in),
-    // both indexed by the pixel's place t in the render order
-    uint32_t* hcnt; const long long* hoff;
-    // thin-lens camera: seed of the per-(pass, pixel) lens streams; reference-stream mode: this pass's lens draws
-    uint32_t seed_lens; const double* lens_u;
-};
-
-__device__ __forceinline__ LensRng make_lens(const EyeParams& ep, int t, int index)
-{
-    LensRng l;
-    l.u = ep.lens_u; l.pos = 0; l.mode = 0; l.xs.seed(1u);
-    if (ep.cam.model == 1) {
-        if (ep.lens_u) { l.mode = 2; l.pos = 2ll * t * (ep.samples * ep.supersamples * ep.supersamples); }
-        else { l.mode = 1; l.xs = make_stream(ep.seed_lens, (uint64_t)ep.pass * (uint64_t)(ep.W * ep.H) + (uint64_t)index); }
-    }
-    return l;
-}
-
-// One pixel of an eye pass: the sy/sx/s loops of src/sppm2.h:628-643 around create_point_loop
-// (:156-315).  t = y*W + x is the pixel's place in the reference's render order.  COMMIT = false runs
-// the same paths without storing anything (used to count draws).
-template <class RNG, bool COMMIT, int GRID = SCENE_ANY>
-__device__ __forceinline__ void eye_pixel(const DevScene& sc, const EyeParams& ep, const HpArrays& hp, const HpArrays& out, int t, RNG& rng, uint32_t& rays)
-{
-    const int P = ep.W * ep.H;
-    const int x = t % ep.W, y = t / ep.W;
-    const int index = (ep.H - y - 1) * ep.W + x;
-    d3 ld = mk(hp.ld[index], hp.ld[P + index], hp.ld[2 * P + index]);
-    int valid = hp.valid[index];
-    bool wrote = false;  // a hitpoint was stored for this pixel in this pass
-    LensRng lens = make_lens(ep, t, index);
-    for (int sy = 0; sy < ep.supersamples; sy++)
-        for (int sx = 0; sx < ep.supersamples; sx++)
-            for (int s = 0; s < ep.samples; s++) {
-                d3 org, dir;
-                if (ep.cam.model == 1) camera_ray_lens(ep.cam, x, y, sx, sy, lens, org, dir);
-                else camera_ray(ep.cam, x, y, sx, sy, org, dir);
-                int depth = -1;
-                bool direct = true;
-                d3 weight = mk(1, 1, 1);
-                for (;;) {
-                    depth++;
-                    Hit is;
-                    rays++;
-                    if (!intersect_scene<GRID>(sc, org, dir, is)) break;
-                    const sppm_sphere* obj = &sc.sp[is.object_id];
-                    const d3 color = ld3(obj->color);
-                    const int type = obj->reflection_type;
-                    const d3 on = dot(is.normal, dir) < 0.0 ? is.normal : is.normal * -1.0;
-                    if (direct) ld = ld + had(weight, ld3(obj->emission));
-                    direct = type != SPPM_DIFFUSE;
-                    if (type == SPPM_DIFFUSE) {
-                        const d3 est = next_event_est<RNG, GRID>(sc, is, on, rng, rays);
-                        ld = ld + had(weight, est);
-                        // create or overwrite the pixel's hitpoint (src/sppm2.h:204-227)
-                        if constexpr (COMMIT) {
-                            out.pos[index] = is.position.x; out.pos[P + index] = is.position.y; out.pos[2 * P + index] = is.position.z;
-                            out.nrm[index] = is.normal.x; out.nrm[P + index] = is.normal.y; out.nrm[2 * P + index] = is.normal.z;
-                            out.w[index] = weight.x; out.w[P + index] = weight.y; out.w[2 * P + index] = weight.z;
-                            out.obj[index] = is.object_id; out.dist[index] = is.distance;
-                            wrote = true;
-                        }
-                        if (!valid) {
-                            valid = 1;
-                            if constexpr (COMMIT) {
-                                hp.r2[index] = ep.initial_r2;
-                                hp.n[index] = 0;  // the reference leaves photon_count unset (src/sppm2.h:108-116); its call site passes 0
-                                hp.flux[index] = 0.0; hp.flux[P + index] = 0.0; hp.flux[2 * P + index] = 0.0;
-                                if (hp.nd) {
-                                    hp.nd[index] = 0.0; hp.madd[index] = 0;
-                                    hp.phi[index] = 0.0; hp.phi[P + index] = 0.0; hp.phi[2 * P + index] = 0.0;
-                                    hp.tau[index] = 0.0; hp.tau[P + index] = 0.0; hp.tau[2 * P + index] = 0.0;
-                                }
-                            }
-                            // the reference's `break` leaves the switch only: fall into the roulette
-                            // block and go round again with the same ray (second direct sample)
-                            if (!ep.double_nee) goto path_done;
-                        } else
-                            goto path_done;
-                    } else if (type == SPPM_SPECULAR) {
-                        org = is.position;
-                        dir = reflect_dir(dir, is.normal);
-                        weight = had(weight, color);
-                    } else {
-                        const d3 rdir = reflect_dir(dir, is.normal);
-                        bool into; double nnt, Re; d3 tdir;
-                        org = is.position;
-                        if (!glass(dir, is.normal, on, true, into, nnt, tdir, Re)) {
-                            dir = rdir;
-                            weight = had(weight, color);
-                        } else {
-                            const double nnt2 = nnt * nnt;
-                            const double Tr = (1.0 - Re) * nnt2;
-                            const double prob = 0.25 + 0.5 * Re;
-                            rng.decision();
-                            if (rng.next01() < prob) {
-                                dir = rdir;
-                                weight = had(weight, color * Re / prob);
-                            } else {
-                                dir = tdir;
-                                weight = had(weight, color * Tr / (1.0 - prob));
-                            }
-                        }
-                    }
-                    {   // Russian roulette, src/sppm2.h:298-313
-                        double rr = max3(color);
-                        if (depth >= SPPM_KDEPTH) {
-                            rr *= ldexp(1.0, -(depth - SPPM_KDEPTH));  // std::pow(0.5, depth - MaxDepth)
-                            rng.decision();
-                            if (rng.next01() >= rr) break;
-                        } else
-                            rr = 1.0;
-                        weight = weight / rr;
-                    }
-                    if (rng.stop()) return;  // sequential-stream samplers only
-                }
-            path_done:;
-            }
-    if constexpr (COMMIT) {
-        // `out` is the view the NEXT gather reads (the eye pass of pass i+1 may run while the gather of pass i
-        // still reads `hp`): the direct term, the valid flag, and -- where this pass stored no hitpoint -- the
-        // hitpoint the pixel already had (the reference overwrites a pixel's hitpoint only on a diffuse hit)
-        out.ld[index] = ld.x; out.ld[P + index] = ld.y; out.ld[2 * P + index] = ld.z;
-        out.valid[index] = valid;
-        if (!wrote && valid) {
-            out.pos[index] = hp.pos[index]; out.pos[P + index] = hp.pos[P + index]; out.pos[2 * P + index] = hp.pos[2 * P + index];
-            out.nrm[index] = hp.nrm[index]; out.nrm[P + index] = hp.nrm[P + index]; out.nrm[2 * P + index] = hp.nrm[2 * P + index];
-            out.w[index] = hp.w[index]; out.w[P + index] = hp.w[P + index]; out.w[2 * P + index] = hp.w[2 * P + index];
-            out.obj[index] = hp.obj[index]; out.dist[index] = hp.dist[index];
-        }
-    }
-}
-
-// One thread per pixel, one XorShift stream per (pass, image index).
-template <int GRID>
-__global__ void __launch_bounds__(256) k_eye_pass(DevScene sc, EyeParams ep, HpArrays hp, HpArrays out, unsigned long long* __restrict__ counters)
-{
-    STAGE_SCENE_T(sc, GRID);
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int P = ep.W * ep.H;
-    uint32_t rays = 0;
-    if (t < P) {
-        const int index = (ep.H - t / ep.W - 1) * ep.W + t % ep.W;
-        XorShift rng = make_stream(ep.seed_eye, (uint64_t)ep.pass * (uint64_t)P + (uint64_t)index);
-        eye_pixel<XorShift, true, GRID>(sc, ep, hp, out, t, rng, rays);
-    }
-    // rays counter: one atomic per wave
-    for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off);
-    if ((threadIdx.x & 63) == 0 && rays) atomicAdd(&counters[0], (unsigned long long)rays);
-}
-
-// ---- classic progressive photon mapping: the eye pass ------------------------------------------------------
-// create_point, src/progressive_photonmapping.h:496-615, for one pixel: the sy/sx/s loops of render()
-// (:769-791) around a recursion that leaves a hitpoint at EVERY diffuse surface it reaches.  Glass follows
-// both branches while depth <= 2 (reflection first, :606-609) and one branch chosen by a draw afterwards
-// (:586-603); roulette from depth > kDepth (:519-524); the weight is a scalar.  The recursion is a loop with
-// a stack: only the refracted branches of depths 0, 1 and 2 can be pending at the same time, and the draws
-// are consumed in the reference's depth-first order.  Hitpoints go to slots base, base+1, ... in creation
-// order (COMMIT); the function returns how many the pixel has.
-#define PPM_DEPTH_LIMIT 64  // kDepthLimit, src/radiance.h:18
-template <class RNG, bool COMMIT>
-__device__ __forceinline__ int ppm_pixel(const DevScene& sc, const EyeParams& ep, const HpArrays& out, int t, long long base, RNG& rng, uint32_t& rays)
-{
-    const int P = out.P;
-    const int x = t % ep.W, y = t / ep.W;
-    int count = 0;
-    for (int sy = 0; sy < ep.supersamples; sy++)
-        for (int sx = 0; sx < ep.supersamples; sx++)
-            for (int s = 0; s < ep.samples; s++) {
-                d3 org, dir;
-                camera_ray(ep.cam, x, y, sx, sy, org, dir);
-                double weight = 1.0;
-                int depth = 0;
-                d3 st_org[3], st_dir[3]; double st_w[3]; int st_depth[3];
-                int sp = 0;
-                for (;;) {  // one create_point call per trip
-                    bool ended = true;
-                    Hit is;
-                    rays++;
-                    if (intersect_scene(sc, org, dir, is)) {
-                        const sppm_sphere* obj = &sc.sp[is.object_id];
-                        const d3 color = ld3(obj->color);
-                        const int type = obj->reflection_type;
-                        const d3 on = dot(is.normal, dir) < 0.0 ? is.normal : is.normal * -1.0;
-                        double rr = max3(color);
-                        if (depth > PPM_DEPTH_LIMIT) rr *= ldexp(1.0, -(depth - PPM_DEPTH_LIMIT));  // std::pow(0.5, depth - kDepthLimit)
-                        bool alive = true;
-                        if (depth > SPPM_KDEPTH) {
-                            rng.decision();
-                            if (rng.next01() >= rr) alive = false;
-                        } else
-                            rr = 1.0;
-                        if (alive) {
-                            if (type == SPPM_DIFFUSE) {  // :529-534
-                                if constexpr (COMMIT) {
-                                    const long long h = base + count;
-                                    const double w = weight / rr;
-                                    out.pos[h] = is.position.x; out.pos[P + h] = is.position.y; out.pos[2 * (long long)P + h] = is.position.z;
-                                    out.nrm[h] = is.normal.x; out.nrm[P + h] = is.normal.y; out.nrm[2 * (long long)P + h] = is.normal.z;
-                                    out.w[h] = w; out.w[P + h] = w; out.w[2 * (long long)P + h] = w;
-                                    out.obj[h] = is.object_id; out.dist[h] = is.distance; out.valid[h] = 1;
-                                    out.r2[h] = ep.initial_r2;
-                                    out.n[h] = 0;  // the constructor drops photon_count (:46-55); its call site passes 0
-                                    out.flux[h] = 0.0; out.flux[P + h] = 0.0; out.flux[2 * (long long)P + h] = 0.0;
-                                }
-                                count++;
-                            } else if (type == SPPM_SPECULAR) {  // :537-544
-                                org = is.position;
-                                dir = reflect_dir(dir, is.normal);
-                                weight = weight / rr;
-                                depth++;
-                                ended = false;
-                            } else {
-                                const d3 rdir = reflect_dir(dir, is.normal);
-                                bool into; double nnt, Re; d3 tdir;
-                                org = is.position;
-                                if (!glass(dir, is.normal, on, false, into, nnt, tdir, Re)) {  // :561-566
-                                    dir = rdir;
-                                    weight = weight / rr;
-                                } else {
-                                    const double nnt2 = nnt * nnt;  // std::pow(nnt, 2.0)
-                                    const double Tr = (1.0 - Re) * nnt2;
-                                    const double prob = 0.25 + 0.5 * Re;
-                                    if (depth > 2) {
-                                        rng.decision();
-                                        if (rng.next01() < prob) { dir = rdir; weight = weight * Re / (prob * rr); }
-                                        else { dir = tdir; weight = weight * Tr / ((1.0 - prob) * rr); }
-                                    } else {  // both: the reflected branch now, the refracted one once that subtree is done
-                                        st_org[sp] = org; st_dir[sp] = tdir; st_w[sp] = weight * Tr / rr; st_depth[sp] = depth + 1;
-                                        sp++;
-                                        dir = rdir;
-                                        weight = weight * Re / rr;
-                                    }
-                                }
-                                depth++;
-                                ended = false;
-                            }
-                        }
-                    }
-                    if (rng.stop()) return count;  // sequential-stream samplers only
-                    if (ended) {
-                        if (sp == 0) break;
-                        sp--;
-                        org = st_org[sp]; dir = st_dir[sp]; weight = st_w[sp]; depth = st_depth[sp];
-                    }
-                }
-            }
-    return count;
-}
-
-// One thread per pixel (t = place in the render order), one XorShift stream per image index.  COMMIT = false
-// counts the pixel's hitpoints (hcnt[t]); COMMIT = true stores them from slot hoff[t] on.
-template <bool COMMIT>
-__global__ void __launch_bounds__(256) k_ppm_eye(DevScene sc, EyeParams ep, HpArrays out, unsigned long long* __restrict__ counters, int32_t* __restrict__ err)
-{
-    STAGE_SCENE(sc);
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int npix = ep.W * ep.H;
-    uint32_t rays = 0;
-    if (t < npix) {
-        const int index = (ep.H - t / ep.W - 1) * ep.W + t % ep.W;
-        XorShift rng = make_stream(ep.seed_eye, (uint64_t)index);
-        const int n = ppm_pixel<XorShift, COMMIT>(sc, ep, out, t, COMMIT ? ep.hoff[t] : 0ll, rng, rays);
-        if constexpr (COMMIT) { if ((long long)n != ep.hoff[t + 1] - ep.hoff[t]) err[5] = 1; }
-        else ep.hcnt[t] = (uint32_t)n;
-    }
-    if constexpr (COMMIT) {
-        for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off);
-        if ((threadIdx.x & 63) == 0 && rays) atomicAdd(&counters[0], (unsigned long long)rays);
-    }
-}
-
-// image assembly of render(), src/progressive_photonmapping.h:807-813: one thread per pixel sums its
-// hitpoints in creation order (the reference walks its kd-sorted vector; the two orders differ by the
-// rounding of a sum of a few terms).
-__global__ void k_ppm_resolve(HpArrays hp, DevScene sc, const long long* __restrict__ hoff, int W, int H, int64_t photon_num, double spp, double* __restrict__ image)
-{
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= W * H) return;
-    const int index = (H - t / W - 1) * W + t % W;
-    const long long P = hp.P;
-    d3 c = mk(0, 0, 0);
-    for (long long h = hoff[t]; h < hoff[t + 1]; h++) {
-        const d3 em = ld3(sc.sp[hp.obj[h]].emission);
-        const d3 flux = mk(hp.flux[h], hp.flux[P + h], hp.flux[2 * P + h]);
-        c = c + (em + flux * hp.w[h] * (1.0 / (SPPM_PI * hp.r2[h] * (double)photon_num))) / spp;
-    }
-    image[3 * (size_t)index] = c.x; image[3 * (size_t)index + 1] = c.y; image[3 * (size_t)index + 2] = c.z;
-}
-
-// ---- reference-stream mode of the eye pass ----------------------------------------------------------
-// The reference draws every pixel's samples from ONE sequential stream (src/sppm2.h:621), so pixel t
-// starts where pixels 0..t-1 stopped.  Most pixels consume a number of draws that does not depend on
-// the values drawn (a diffuse first hit: the light samples only); the rest (a glass vertex, roulette
-// from depth 5 on) are "dynamic".  Three kernels: count/classify in parallel, one wavefront walks the
-// pixels in render order and resolves the dynamic ones with the real stream, then the pass itself runs
-// in parallel from the offsets found.  DYN_PIXEL marks a dynamic pixel in cnt[].
-#define DYN_PIXEL 0x80000000u
-template <int ALGO>  // 0: sppm2.h, 1: progressive_photonmapping.h
-__global__ void __launch_bounds__(256) k_eye_classify(DevScene sc, EyeParams ep, HpArrays hp)
-{
-    STAGE_SCENE(sc);
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= ep.W * ep.H) return;
-    ProbeRng rng;
-    rng.count = 0; rng.dyn = false;
-    uint32_t rays = 0;
-    if constexpr (ALGO == 0) eye_pixel<ProbeRng, false>(sc, ep, hp, hp, t, rng, rays);
-    else (void)ppm_pixel<ProbeRng, false>(sc, ep, hp, t, 0ll, rng, rays);
-    ep.cnt[t] = rng.dyn ? DYN_PIXEL : (uint32_t)rng.count;
-}
-
-template <int ALGO>
-__global__ void __launch_bounds__(64) k_eye_offsets(DevScene sc, EyeParams ep, HpArrays hp, int32_t* __restrict__ err)
-{
-    STAGE_SCENE(sc);
-    const int lane = threadIdx.x;
-    const int P = ep.W * ep.H;
-    unsigned long long cur = 0;
-    for (int base = 0; base < P; base += 64) {
-        const int t = base + lane;
-        const uint32_t c = t < P ? ep.cnt[t] : 0u;
-        const unsigned long long dyn = __ballot(t < P && (c & DYN_PIXEL) != 0u);
-        int pos = 0;
-        while (pos < 64) {
-            const unsigned long long rest = dyn & (pos == 0 ? ~0ull : (~0ull << pos));
-            const int f = rest ? __ffsll((long long)rest) - 1 : 64;
-            // lanes [pos, f): offsets from a prefix sum of their fixed counts
-            const bool in = lane >= pos && lane < f;
-            unsigned long long incl = in ? (unsigned long long)c : 0ull;
-            for (int o = 1; o < 64; o <<= 1) { const unsigned long long y = __shfl_up(incl, o); if (lane >= o) incl += y; }
-            if (in && t < P) ep.off[t] = cur + incl - c;
-            cur += __shfl(incl, 63);
-            if (f < 64) {  // the dynamic pixel: run its paths on the real stream to see where it stops
-                unsigned long long used = 0;
-                if (lane == f) {
-                    ep.off[t] = cur;
-                    StreamRng rng; rng.u = ep.u; rng.pos = (int64_t)cur; rng.end = ep.u_len;
-                    uint32_t rays = 0;
-                    if constexpr (ALGO == 0) eye_pixel<StreamRng, false>(sc, ep, hp, hp, t, rng, rays);
-                    else (void)ppm_pixel<StreamRng, false>(sc, ep, hp, t, 0ll, rng, rays);
-                    used = (unsigned long long)rng.pos - cur;
-                    if (rng.stop()) err[4] = 1;
-                }
-                cur += __shfl(used, f);
-            }
-            pos = f + 1;
-        }
-    }
-    if (lane == 0) { ep.total[0] = cur; if ((int64_t)cur > ep.u_len) err[4] = 1; }
-}
-
-__global__ void __launch_bounds__(256) k_eye_pass_stream(DevScene sc, EyeParams ep, HpArrays hp, HpArrays out, unsigned long long* __restrict__ counters,
-                                                        int32_t* __restrict__ err)
-{
-    STAGE_SCENE(sc);
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int P = ep.W * ep.H;
-    uint32_t rays = 0;
-    if (t < P) {
-        StreamRng rng; rng.u = ep.u; rng.pos = (int64_t)ep.off[t]; rng.end = ep.u_len;
-        eye_pixel<StreamRng, true>(sc, ep, hp, out, t, rng, rays);
-        // the pixel must stop exactly where the walk said the next one starts
-        const unsigned long long next = t + 1 < P ? ep.off[t + 1] : ep.total[0];
-        if ((unsigned long long)rng.pos != next) err[5] = 1;
-    }
-    for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off);
-    if ((threadIdx.x & 63) == 0 && rays) atomicAdd(&counters[0], (unsigned long long)rays);
-}
-
-// classic PPM on the reference's stream: pixel t reads from off[t]; COMMIT as in k_ppm_eye
-template <bool COMMIT>
-__global__ void __launch_bounds__(256) k_ppm_eye_stream(DevScene sc, EyeParams ep, HpArrays out, unsigned long long* __restrict__ counters, int32_t* __restrict__ err)
-{
-    STAGE_SCENE(sc);
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int npix = ep.W * ep.H;
-    uint32_t rays = 0;
-    if (t < npix) {
-        StreamRng rng; rng.u = ep.u; rng.pos = (int64_t)ep.off[t]; rng.end = ep.u_len;
-        const int n = ppm_pixel<StreamRng, COMMIT>(sc, ep, out, t, COMMIT ? ep.hoff[t] : 0ll, rng, rays);
-        const unsigned long long next = t + 1 < npix ? ep.off[t + 1] : ep.total[0];
-        if ((unsigned long long)rng.pos != next) err[5] = 1;
-        if constexpr (COMMIT) { if ((long long)n != ep.hoff[t + 1] - ep.hoff[t]) err[5] = 1; }
-        else ep.hcnt[t] = (uint32_t)n;
-    }
-    if constexpr (COMMIT) {
-        for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off);
-        if ((threadIdx.x & 63) == 0 && rays) atomicAdd(&counters[0], (unsigned long long)rays);
-    }
-}
-
-struct TraceParams {
-    int pass; int64_t first, count, photons_per_pass; uint32_t seed_photon; double flux_scale;
-    int64_t rec_cap;
-    // reference-stream mode only
-    const double* u; int64_t u_len; const uint32_t* start; uint32_t* consumed;
-    // classic PPM (src/progressive_photonmapping.h:326,339,344,385-387): depth starts at 0, so the first diffuse
-    // hit deposits too, and the flux that reaches a hitpoint is multiply(obj.color, current_flux) of the PHOTON's
-    // surface: the record stores that product
-    int ppm;
-};
-struct RecArrays { uint64_t* key; double* f; int64_t cap; };  // f[9][cap]
-
-// create_photon, src/sppm2.h:317-525, with the kd search + update replaced by appending a photon-hit
-// record (diffuse hit, depth > 0).  Photon paths have very different lengths (the longest of 64 is
-// ~3x the mean), so lanes are not bound to photons: a lane whose photon has ended takes the next
-// photon index of its wavefront's current block of 64 (blocks come from one global counter), emits it,
-// and all lanes then advance one bounce together.  Which lane traces which photon does not matter:
-// the stream is keyed by the photon index and records are ordered by key later.
-//
-// MODE 0: one XorShift stream per photon.
-// Reference-stream mode (the photons of a pass share ONE sequential stream, src/sppm2.h:530):
-// MODE 2: "photon" i is a path started at stream offset i; no records, consumed[i] = draws it used.
-//         Following consumed[] from offset 0 (k_photon_chain) gives every real photon's start offset.
-// MODE 1: photon i reads the stream from start[i]; records as in mode 0.
-template <class RNG> struct PhotonState { RNG rng; d3 org, dir, flux; int depth; int64_t index; };
-struct Deposit { bool want; unsigned long long key; d3 pos, nrm, flux; };
-#define STREAM_OVER 0xFFFFFFFFu
-
-template <int MODE, class RNG>
-__device__ __forceinline__ void photon_emit(const DevScene& sc, const TraceParams& tp, int64_t i, PhotonState<RNG>& ps)
-{
-    ps.index = i;
-    if constexpr (MODE == 0) ps.rng = make_stream(tp.seed_photon, (uint64_t)tp.pass * (uint64_t)tp.photons_per_pass + (uint64_t)i);
-    else { ps.rng.u = tp.u; ps.rng.end = tp.u_len; ps.rng.pos = MODE == 1 ? (int64_t)tp.start[i] : i; }
-    (void)ps.rng.next01(); (void)ps.rng.next01();  // two draws computed and discarded, src/sppm2.h:322-324
-    const double r1 = 2 * SPPM_PI * ps.rng.next01();
-    const double r2 = 1.0 - 2.0 * ps.rng.next01();
-    const double r3 = 1.0 - r2 * r2;
-    double sn, cs;
-    dm_sincos(r1, &sn, &cs);
-    const d3 lc = ld3(sc.sp[0].position);
-    const d3 source_pos = lc + mk(sqrt(r3) * cs, sqrt(r3) * sn, r2) * (sc.sp[0].radius + SPPM_EPS);
-    const d3 w = normalize(source_pos - lc);
-    d3 u, v;
-    basis(w, u, v);
-    ps.org = source_pos;
-    ps.dir = cosine_sampling(w, u, v, ps.rng);
-    ps.flux = ld3(sc.sp[0].emission) * 4.0 * tp.flux_scale;
-    ps.depth = tp.ppm ? 0 : -1;
-}
-
-// one iteration of the while loop of create_photon; returns false when the path ends
-template <class RNG, int GRID>
-__device__ __forceinline__ bool photon_bounce(const DevScene& sc, PhotonState<RNG>& ps, Deposit& dep, int32_t* __restrict__ err, uint32_t& rays, const bool ppm)
-{
-    if (ps.rng.stop()) return false;
-    if (max3(ps.flux) <= 0.0) return false;
-    Hit is;
-    rays++;
-    if (!intersect_scene<GRID>(sc, ps.org, ps.dir, is)) return false;
-    const sppm_sphere* obj = &sc.sp[is.object_id];
-    const d3 color = ld3(obj->color);
-    const int type = obj->reflection_type;
-    const bool flip = !(dot(is.normal, ps.dir) < 0.0);
-    const d3 on = flip ? is.normal * -1.0 : is.normal;
-    ps.depth++;
-    if (type == SPPM_DIFFUSE) {
-        if (ps.depth > 0) {
-            if (ps.depth > 32767) { err[1] = 1; return false; }
-            // the record is stored by the caller, where the whole wavefront has reconverged
-            dep.want = true;
-            dep.key = ((uint64_t)ps.index << 16) | ((uint64_t)ps.depth << 1) | (flip ? 1ull : 0ull);
-            dep.pos = is.position; dep.nrm = is.normal; dep.flux = ppm ? had(color, ps.flux) : ps.flux;
-        }
-        const double prob = (color.x + color.y + color.z) / 3;
-        if (!(prob > ps.rng.next01())) return false;
-        d3 du, dv;
-        basis(on, du, dv);
-        ps.dir = cosine_sampling(on, du, dv, ps.rng);
-        ps.org = is.position;
-        ps.flux = had(ps.flux, color) / prob;
-    } else if (type == SPPM_SPECULAR) {
-        ps.dir = reflect_dir(ps.dir, is.normal);
-        ps.org = is.position;
-        ps.flux = had(ps.flux, color);
-    } else {
-        const d3 rdir = reflect_dir(ps.dir, is.normal);
-        bool into; double nnt, Re; d3 tdir;
-        ps.org = is.position;
-        if (!glass(ps.dir, is.normal, on, false, into, nnt, tdir, Re)) ps.dir = rdir;
-        else ps.dir = (ps.rng.next01() < Re) ? rdir : tdir;
-        ps.flux = had(ps.flux, color);
-    }
-    return true;
-}
-
-template <int MODE> struct TraceRng { typedef StreamRng type; };
-template <> struct TraceRng<0> { typedef XorShift type; };
-
-#define TRACE_GRAB 64
-#define REC_CHUNK 128  // record slots a wavefront reserves at a time (one atomic per chunk instead of one per record)
-#define REC_INVALID (~0ull)
-template <int MODE, int GRID>
-__global__ void __launch_bounds__(256) k_photon_trace(DevScene sc, TraceParams tp, RecArrays rec, unsigned long long* __restrict__ rec_count,
-                                                      unsigned long long* __restrict__ next_block, unsigned long long* __restrict__ counters,
-                                                      int32_t* __restrict__ err)
-{
-    typedef typename TraceRng<MODE>::type RNG;
-    STAGE_SCENE_T(sc, GRID);
-    const int lane = threadIdx.x & 63;
-    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    uint32_t rays = 0;
-    PhotonState<RNG> ps;
-    ps.depth = 0; ps.index = 0; ps.org = mk(0, 0, 0); ps.dir = mk(0, 0, 1); ps.flux = mk(0, 0, 0);
-    if constexpr (MODE == 0) ps.rng.seed(1u); else { ps.rng.u = tp.u; ps.rng.pos = 0; ps.rng.end = tp.u_len; }
-    bool active = false, exhausted = false;
-    int64_t blk_lo = 0, blk_hi = 0;  // wave-uniform: the unassigned rest of this wave's current block
-    int64_t chunk_lo = 0, chunk_hi = 0;  // wave-uniform: the unused rest of this wave's reserved record slots
-    bool rec_full = false;
-    for (;;) {
-        const unsigned long long need = __ballot(!active);
-        if (need != 0 && !exhausted) {
-            if (blk_lo >= blk_hi) {
-                unsigned long long base = 0;
-                if (lane == 0) base = atomicAdd(next_block, (unsigned long long)TRACE_GRAB);
-                base = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) |
-                       (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)base);
-                blk_lo = (int64_t)base;
-                blk_hi = min((int64_t)base + TRACE_GRAB, tp.count);
-                if (blk_lo >= tp.count) { exhausted = true; blk_lo = blk_hi = 0; }
-            }
-            const int64_t idx = blk_lo + __popcll(need & lt_mask);
-            if (!active && idx < blk_hi) { photon_emit<MODE>(sc, tp, tp.first + idx, ps); active = true; }
-            blk_lo = min(blk_hi, blk_lo + (int64_t)__popcll(need));
-        }
-        if (__ballot(active) == 0) { if (exhausted) break; else continue; }
-        Deposit dep;
-        dep.want = false;
-        if (active) {
-            active = photon_bounce<RNG, GRID>(sc, ps, dep, err, rays, tp.ppm != 0);
-            if constexpr (MODE == 2)
-                if (!active) tp.consumed[ps.index] = ps.rng.stop() ? STREAM_OVER : (uint32_t)(ps.rng.pos - ps.index);
-            if constexpr (MODE == 1)
-                if (!active && ps.rng.stop()) err[4] = 1;
-        }
-        if constexpr (MODE == 2) continue;
-        // store the records of this step: slots come from the wave's chunk, a new chunk costs one atomic
-        const unsigned long long dm = __ballot(dep.want);
-        if (dm != 0 && !rec_full) {
-            const int cnt = __popcll(dm);
-            if (chunk_lo + cnt > chunk_hi) {
-                if (lane < chunk_hi - chunk_lo) rec.key[chunk_lo + lane] = REC_INVALID;  // fewer than 64 left: mark them as holes
-                unsigned long long base = 0;
-                if (lane == 0) base = atomicAdd(rec_count, (unsigned long long)REC_CHUNK);
-                base = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) |
-                       (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)base);
-                chunk_lo = (int64_t)base;
-                chunk_hi = (int64_t)base + REC_CHUNK;
-                if (chunk_hi > rec.cap) { rec_full = true; chunk_lo = chunk_hi = 0; if (lane == 0) err[0] = 1; }
-            }
-            if (!rec_full) {
-                if (dep.want) {
-                    const int64_t slot = chunk_lo + __popcll(dm & lt_mask);
-                    rec.key[slot] = dep.key;
-                    double* f = rec.f + slot;
-                    const int64_t c = rec.cap;
-                    f[0] = dep.pos.x; f[c] = dep.pos.y; f[2 * c] = dep.pos.z;
-                    f[3 * c] = dep.nrm.x; f[4 * c] = dep.nrm.y; f[5 * c] = dep.nrm.z;
-                    f[6 * c] = dep.flux.x; f[7 * c] = dep.flux.y; f[8 * c] = dep.flux.z;
-                }
-                chunk_lo += cnt;
-            }
-        }
-    }
-    for (int64_t j = chunk_lo + lane; j < chunk_hi; j += 64) rec.key[j] = REC_INVALID;
-    for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off);
-    if (MODE != 2 && lane == 0 && rays) atomicAdd(&counters[1], (unsigned long long)rays);  // [1]: rays cast by photon tracing
-}
-
-// Reference-stream mode: photon 0 starts at offset 0, photon i+1 where photon i stopped.  One
-// wavefront follows consumed[] through an LDS window (the chain is sequential; each step is one LDS read).
-#define CHAIN_WINDOW 2048
-__global__ void __launch_bounds__(64) k_photon_chain(const uint32_t* __restrict__ consumed, int64_t u_len, int64_t count, uint32_t* __restrict__ start,
-                                                     unsigned long long* __restrict__ total, int32_t* __restrict__ err)
-{
-    __shared__ uint32_t win[CHAIN_WINDOW];
-    const int lane = threadIdx.x;
-    int64_t cur = 0, wbase = -(int64_t)CHAIN_WINDOW;
-    bool bad = false;
-    for (int64_t i = 0; i < count; i++) {
-        if (cur >= u_len) { bad = true; break; }
-        if (cur >= wbase + CHAIN_WINDOW) {
-            __syncthreads();
-            wbase = cur;
-            for (int k = lane; k < CHAIN_WINDOW; k += 64) win[k] = wbase + k < u_len ? consumed[wbase + k] : STREAM_OVER;
-            __syncthreads();
-        }
-        const uint32_t c = win[cur - wbase];
-        if (c == STREAM_OVER) { bad = true; break; }
-        if (lane == 0) start[i] = (uint32_t)cur;
-        cur += c;
-    }
-    if (lane == 0) { total[0] = (unsigned long long)cur; if (bad) err[4] = 1; }
-}
-
-// ---- hash grid over the records of a batch ----------------------------------------------------------
-struct Grid { double inv_cell; uint32_t mask; };
-
-__device__ __forceinline__ int cell_coord(double x, double inv_cell) { return (int)floor(x * inv_cell); }
-__device__ __forceinline__ uint32_t cell_hash(int ix, int iy, int iz, uint32_t mask)
-{
-    return (((uint32_t)ix * 73856093u) ^ ((uint32_t)iy * 19349663u) ^ ((uint32_t)iz * 83492791u)) & mask;
-}
-
-__global__ void k_grid_count(RecArrays rec, const unsigned long long* __restrict__ rec_count, Grid g, uint32_t* __restrict__ cell_cnt,
-                             uint32_t* __restrict__ rec_bucket)
-{
-    const int64_t n = min((int64_t)*rec_count, rec.cap);
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        if (rec.key[i] == REC_INVALID) { rec_bucket[i] = 0xFFFFFFFFu; continue; }  // a hole left by the tracer's chunked slot reservation
-        const uint32_t b = cell_hash(cell_coord(rec.f[i], g.inv_cell), cell_coord(rec.f[rec.cap + i], g.inv_cell),
-                                     cell_coord(rec.f[2 * rec.cap + i], g.inv_cell), g.mask);
-        rec_bucket[i] = b;
-        atomicAdd(&cell_cnt[b], 1u);
-    }
-}
-
-// exclusive scan of cell_cnt[0..n) -> cell_start[0..n], three small kernels (n is a power of two >= 1024)
-#define SCAN_BLOCK 1024
-__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_blocks(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t* __restrict__ block_sum)
-{
-    __shared__ uint32_t wave_tot[SCAN_BLOCK / 64];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const size_t i = (size_t)blockIdx.x * SCAN_BLOCK + tid;
-    const uint32_t v = in[i];
-    uint32_t x = v;
-    for (int off = 1; off < 64; off <<= 1) { const uint32_t y = __shfl_up(x, off); if (lane >= off) x += y; }
-    if (lane == 63) wave_tot[wv] = x;
-    __syncthreads();
-    if (wv == 0) {
-        uint32_t t = lane < SCAN_BLOCK / 64 ? wave_tot[lane] : 0;
-        for (int off = 1; off < SCAN_BLOCK / 64; off <<= 1) { const uint32_t y = __shfl_up(t, off); if (lane >= off) t += y; }
-        if (lane < SCAN_BLOCK / 64) wave_tot[lane] = t;
-    }
-    __syncthreads();
-    const uint32_t base = wv ? wave_tot[wv - 1] : 0;
-    out[i] = base + x - v;
-    if (tid == SCAN_BLOCK - 1) block_sum[blockIdx.x] = base + x;
-}
-__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_tops(uint32_t* __restrict__ block_sum, int nblocks, uint32_t* __restrict__ total_out,
-                                                          unsigned long long* __restrict__ records_acc)
-{
-    // single block; nblocks <= 16384 handled by a serial carry over chunks of SCAN_BLOCK
-    __shared__ uint32_t wave_tot[SCAN_BLOCK / 64];
-    __shared__ uint32_t carry;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (tid == 0) carry = 0;
-    __syncthreads();
-    for (int base_i = 0; base_i < nblocks; base_i += SCAN_BLOCK) {
-        const int i = base_i + tid;
-        const uint32_t v = i < nblocks ? block_sum[i] : 0;
-        uint32_t x = v;
-        for (int off = 1; off < 64; off <<= 1) { const uint32_t y = __shfl_up(x, off); if (lane >= off) x += y; }
-        if (lane == 63) wave_tot[wv] = x;
-        __syncthreads();
-        if (wv == 0) {
-            uint32_t t = lane < SCAN_BLOCK / 64 ? wave_tot[lane] : 0;
-            for (int off = 1; off < SCAN_BLOCK / 64; off <<= 1) { const uint32_t y = __shfl_up(t, off); if (lane >= off) t += y; }
-            if (lane < SCAN_BLOCK / 64) wave_tot[lane] = t;
-        }
-        __syncthreads();
-        const uint32_t b = carry + (wv ? wave_tot[wv - 1] : 0);
-        if (i < nblocks) block_sum[i] = b + x - v;
-        __syncthreads();
-        if (tid == SCAN_BLOCK - 1) carry = b + x;
-        __syncthreads();
-    }
-    if (tid == 0) { *total_out = carry; if (records_acc) atomicAdd(records_acc, (unsigned long long)carry); }
-}
-__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_add(uint32_t* __restrict__ out, const uint32_t* __restrict__ block_sum, uint32_t* __restrict__ cursor,
-                                                         size_t n, const uint32_t* __restrict__ total)
-{
-    const size_t i = (size_t)blockIdx.x * SCAN_BLOCK + threadIdx.x;
-    const uint32_t v = out[i] + block_sum[blockIdx.x];
-    out[i] = v;
-    cursor[i] = v;
-    if (i == n - 1) out[n] = *total;
-}
-__global__ void k_grid_scatter(RecArrays src, RecArrays dst, const unsigned long long* __restrict__ rec_count,
-                               const uint32_t* __restrict__ rec_bucket, uint32_t* __restrict__ cursor)
-{
-    const int64_t n = min((int64_t)*rec_count, src.cap);
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        if (rec_bucket[i] == 0xFFFFFFFFu) continue;
-        const uint32_t p = atomicAdd(&cursor[rec_bucket[i]], 1u);
-        dst.key[p] = src.key[i];
-#pragma unroll
-        for (int c = 0; c < 9; c++) dst.f[c * dst.cap + p] = src.f[c * src.cap + i];
-    }
-}
-
-// max over valid hitpoints of min(r2, gather_r2), as an ordered-int atomic max on the bit pattern
-struct Own { const uint8_t* mask; };  // mask[p] != 0: this rank owns pixel p
-__device__ __forceinline__ bool owned(const Own& o, int p) { return o.mask[p] != 0; }
-__global__ void k_mask_from_list(const int32_t* __restrict__ pix, int n, uint8_t* __restrict__ mask)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) mask[pix[i]] = 1;
-}
-__global__ void k_r2max(HpArrays hp, Own own, double gather_r2, unsigned long long* __restrict__ out)
-{
-    double m = 0.0;
-    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < hp.P; p += gridDim.x * blockDim.x) {
-        if (hp.valid[p] && owned(own, p)) { const double r = fmin(hp.r2[p], gather_r2); m = fmax(m, r); }
-    }
-    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_down(m, off));
-    if ((threadIdx.x & 63) == 0 && m > 0.0) atomicMax(out, (unsigned long long)__double_as_longlong(m));
-}
-
-// ---- gather: each hitpoint replays the records near it in key order ------------------------------------
-struct GatherParams {
-    Grid g; double gather_r2, alpha; int rule; Own own;
-    int unit_weight;  // classic PPM: the record's flux is applied as it is (no hitpoint weight or colour)
-    uint64_t* tap_key; int32_t* tap_pix; unsigned long long* tap_n; int64_t tap_cap;
-};
-
-#define SEL 8  // keys selected per scan of the neighbourhood
-
-// Does record r pass the search filter of src/kdtree.h:123-127 and the acceptance test of
-// src/sppm2.h:393-395 for a hitpoint at hpos with normal hn and squared radius r2?
-__device__ __forceinline__ bool rec_accept(const RecArrays& rec, int64_t r, uint64_t key, d3 hpos, d3 hn, double r2, double gather_r2)
-{
-    const int64_t c = rec.cap;
-    const d3 q = mk(rec.f[r], rec.f[c + r], rec.f[2 * c + r]);
-    const d3 dir = hpos - q;  // node position - search position, kdtree.h:123
-    const double d2 = len2(dir);
-    if (!(d2 < gather_r2) || !(d2 <= r2)) return false;
-    const d3 gn = mk(rec.f[3 * c + r], rec.f[4 * c + r], rec.f[5 * c + r]);
-    if (!(dot(hn, gn) > 1e-3)) return false;
-    const d3 on = (key & 1ull) ? gn * -1.0 : gn;
-    const double dt = dot(on, dir / sqrt(d2));           // NaN when d2 == 0: rejected, as in the reference
-    return fabs(dt) <= gather_r2 * 0.01;
-}
-
-__global__ void __launch_bounds__(256) k_gather(HpArrays hp, DevScene sc, RecArrays rec, const uint32_t* __restrict__ cell_start, GatherParams gp,
-                                                unsigned long long* __restrict__ counters)
-{
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t n_cand = 0, n_acc = 0;
-    if (t < hp.P) {
-        const int p = t;
-        const int P = hp.P;
-        if (hp.valid[p] && owned(gp.own, p)) {
-            const d3 hpos = mk(hp.pos[p], hp.pos[P + p], hp.pos[2 * P + p]);
-            const d3 hn = mk(hp.nrm[p], hp.nrm[P + p], hp.nrm[2 * P + p]);
-            const d3 hw = gp.unit_weight ? mk(1, 1, 1) : mk(hp.w[p], hp.w[P + p], hp.w[2 * P + p]);
-            const d3 hcol = gp.unit_weight ? mk(1, 1, 1) : ld3(sc.sp[hp.obj[p]].color);
-            double r2 = hp.r2[p];
-            int n = 0; double nd = 0.0; int madd = 0;
-            d3 acc;
-            if (gp.rule == 0) { n = hp.n[p]; acc = mk(hp.flux[p], hp.flux[P + p], hp.flux[2 * P + p]); }
-            else { madd = hp.madd[p]; acc = mk(hp.phi[p], hp.phi[P + p], hp.phi[2 * P + p]); }
-            // cells overlapping the sphere of the larger of the two bounds the tests use
-            const double rr = sqrt(fmin(r2, gp.gather_r2)) * (1.0 + 1e-9) + 1e-12;
-            const int x0 = cell_coord(hpos.x - rr, gp.g.inv_cell), x1 = cell_coord(hpos.x + rr, gp.g.inv_cell);
-            const int y0 = cell_coord(hpos.y - rr, gp.g.inv_cell), y1 = cell_coord(hpos.y + rr, gp.g.inv_cell);
-            const int z0 = cell_coord(hpos.z - rr, gp.g.inv_cell), z1 = cell_coord(hpos.z + rr, gp.g.inv_cell);
-            uint64_t last = 0;  // keys are > 0: depth >= 1
-            for (;;) {
-                // select the SEL smallest keys > last among accepted candidates (sorted ascending)
-                uint64_t sk[SEL]; int64_t si[SEL];
-#pragma unroll
-                for (int j = 0; j < SEL; j++) { sk[j] = ~0ull; si[j] = -1; }
-                for (int iz = z0; iz <= z1; iz++)
-                    for (int iy = y0; iy <= y1; iy++)
-                        for (int ix = x0; ix <= x1; ix++) {
-                            const uint32_t b = cell_hash(ix, iy, iz, gp.g.mask);
-                            const uint32_t e = cell_start[b + 1];
-                            for (uint32_t r = cell_start[b]; r < e; r++) {
-                                const uint64_t key = rec.key[r];
-                                if (last == 0) n_cand++;
-                                if (key <= last || key >= sk[SEL - 1]) continue;
-                                if (!rec_accept(rec, r, key, hpos, hn, r2, gp.gather_r2)) continue;
-                                // two cells of the range may share a bucket: skip a key already held
-                                bool dup = false;
-#pragma unroll
-                                for (int j = 0; j < SEL; j++) dup |= (sk[j] == key);
-                                if (dup) continue;
-                                uint64_t ck = key; int64_t ci = r;
-#pragma unroll
-                                for (int j = 0; j < SEL; j++) {
-                                    if (ck < sk[j]) { const uint64_t tk = sk[j]; const int64_t ti = si[j]; sk[j] = ck; si[j] = ci; ck = tk; ci = ti; }
-                                }
-                            }
-                        }
-                if (si[0] < 0) break;
-#pragma unroll
-                for (int j = 0; j < SEL; j++) {
-                    if (si[j] < 0) continue;
-                    const int64_t r = si[j];
-                    last = sk[j];
-                    // the radius may have shrunk since the scan: test again with the current one
-                    if (!rec_accept(rec, r, sk[j], hpos, hn, r2, gp.gather_r2)) continue;
-                    const int64_t c = rec.cap;
-                    const d3 pf = mk(rec.f[6 * c + r], rec.f[7 * c + r], rec.f[8 * c + r]);
-                    if (gp.rule == 0) {  // src/sppm2.h:397-419
-                        double g;
-                        if (n != 0) g = (n * gp.alpha + gp.alpha) / (n * gp.alpha + 1.0);
-                        else g = 1;
-                        r2 = r2 * g;
-                        n++;
-                        acc = (acc + had(hw, had(hcol, pf)) / SPPM_PI) * g;
-                    } else {             // src/stochastic_ppm.h:449-454
-                        const d3 f = hcol / SPPM_PI;
-                        acc = acc + had(pf, f);
-                        madd++;
-                    }
-                    n_acc++;
-                    if (gp.tap_cap > 0) {
-                        const unsigned long long slot = atomicAdd(gp.tap_n, 1ull);
-                        if ((int64_t)slot < gp.tap_cap) { gp.tap_key[slot] = sk[j]; gp.tap_pix[slot] = p; }
-                    }
-                }
-                if (si[SEL - 1] < 0) break;  // the scan found fewer than SEL: nothing is left
-            }
-            if (gp.rule == 0) {
-                hp.r2[p] = r2; hp.n[p] = n;
-                hp.flux[p] = acc.x; hp.flux[P + p] = acc.y; hp.flux[2 * P + p] = acc.z;
-            } else {
-                hp.madd[p] = madd;
-                hp.phi[p] = acc.x; hp.phi[P + p] = acc.y; hp.phi[2 * P + p] = acc.z;
-            }
-            (void)nd;
-        }
-    }
-    for (int off = 32; off > 0; off >>= 1) { n_cand += __shfl_down(n_cand, off); n_acc += __shfl_down(n_acc, off); }
-    if ((threadIdx.x & 63) == 0) {
-        if (n_cand) atomicAdd(&counters[3], (unsigned long long)n_cand);
-        if (n_acc) atomicAdd(&counters[4], (unsigned long long)n_acc);
-    }
-}
-
-// ---- K cap check (cfg.check_gather_max) ------------------------------------------------------------------
-// The reference's search keeps at most K hitpoints per photon hit (src/kdtree.h:128-133).  While no query
-// holds more than K candidates the cap never acts and the uncapped set this build computes IS the
-// reference's set.  This kernel counts, for every record of the batch, the hitpoints that pass the search
-// filter of kdtree.h:123-127 (d2 < R^2 and |dot(on, dir/|dir|)| <= 0.01 R^2) -- ALL hitpoints, not only those
-// whose own radius still reaches the record -- by brute force: a block of 256 records against the hitpoint
-// positions staged through LDS.  A validation mode: exact, O(records x hitpoints).
-__global__ void __launch_bounds__(256) k_count_queries(HpArrays hp, RecArrays rec, const unsigned long long* __restrict__ rec_count, double gather_r2,
-                                                       long long K, int32_t* __restrict__ err, unsigned long long* __restrict__ qmax)
-{
-    __shared__ double s_p[3][256];
-    const long long slots = min((long long)*rec_count, (long long)rec.cap);
-    if ((long long)blockIdx.x * 256 >= slots) return;
-    const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long cap = rec.cap, P = hp.P;
-    bool have = false;
-    unsigned long long key = 0;
-    d3 q = mk(0, 0, 0), on = mk(0, 0, 0);
-    if (r < slots) {
-        key = rec.key[r];
-        have = key != REC_INVALID;
-        if (have) {
-            q = mk(rec.f[r], rec.f[cap + r], rec.f[2 * cap + r]);
-            const d3 gn = mk(rec.f[3 * cap + r], rec.f[4 * cap + r], rec.f[5 * cap + r]);
-            on = (key & 1ull) ? gn * -1.0 : gn;
-        }
-    }
-    const double thr = gather_r2 * 0.01;
-    long long cnt = 0;
-    for (long long base = 0; base < P; base += 256) {
-        const long long h = base + threadIdx.x;
-        const bool live = h < P && hp.valid[h] != 0;
-        // a hitpoint that does not exist sits infinitely far away
-        s_p[0][threadIdx.x] = live ? hp.pos[h] : 1e300; s_p[1][threadIdx.x] = live ? hp.pos[P + h] : 1e300; s_p[2][threadIdx.x] = live ? hp.pos[2 * P + h] : 1e300;
-        __syncthreads();
-        if (have) {
-            for (int j = 0; j < 256; j++) {
-                const d3 dir = mk(s_p[0][j], s_p[1][j], s_p[2][j]) - q;
-                const double d2 = len2(dir);
-                if (d2 < gather_r2) {
-                    const double dt = dot(on, dir / sqrt(d2));  // NaN at d2 == 0: rejected, as in the reference
-                    if (fabs(dt) <= thr) cnt++;
-                }
-            }
-        }
-        __syncthreads();
-    }
-    if (have) {
-        if (cnt > K) err[2] = 1;
-        atomicMax(qmax, (unsigned long long)cnt);
-    }
-}
-
-// ---- hitpoint state between ranks ------------------------------------------------------------------------
-// out[h][5] = (r2, flux xyz, N) of the hitpoints this rank owns, zeros elsewhere: summed over the ranks (exactly
-// one non-zero term per hitpoint, so the sum is exact) it is the state of a single-GPU run.
-__global__ void k_export_state(HpArrays hp, Own own, double* __restrict__ out)
-{
-    const long long h = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long P = hp.P;
-    if (h >= P) return;
-    const bool mine = hp.valid[h] != 0 && owned(own, (int)h);
-    double* o = out + 5 * h;
-    o[0] = mine ? hp.r2[h] : 0.0;
-    o[1] = mine ? hp.flux[h] : 0.0; o[2] = mine ? hp.flux[P + h] : 0.0; o[3] = mine ? hp.flux[2 * P + h] : 0.0;
-    o[4] = mine ? (double)hp.n[h] : 0.0;
-}
-__global__ void k_import_state(HpArrays hp, const double* __restrict__ in)
-{
-    const long long h = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long P = hp.P;
-    if (h >= P) return;
-    if (!hp.valid[h]) return;
-    const double* o = in + 5 * h;
-    hp.r2[h] = o[0];
-    hp.flux[h] = o[1]; hp.flux[P + h] = o[2]; hp.flux[2 * P + h] = o[3];
-    hp.n[h] = (int32_t)o[4];
-}
-
-// end-of-pass update of rule 1, src/stochastic_ppm.h:721-741
-__global__ void k_end_pass(HpArrays hp, Own own, double alpha)
-{
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    const int P = hp.P;
-    if (p >= P) return;
-    if (!hp.valid[p] || !owned(own, p)) return;
-    const int madd = hp.madd[p];
-    if (madd > 0) {
-        const double N = hp.nd[p], r2 = hp.r2[p];
-        const double Nnew = N + alpha * madd;
-        const double Rnew2 = r2 * Nnew / (N + madd);
-        const d3 tau = mk(hp.tau[p], hp.tau[P + p], hp.tau[2 * P + p]);
-        const d3 phi = mk(hp.phi[p], hp.phi[P + p], hp.phi[2 * P + p]);
-        const d3 w = mk(hp.w[p], hp.w[P + p], hp.w[2 * P + p]);
-        const d3 tn = (tau + had(phi, w)) * Rnew2 / r2;
-        hp.tau[p] = tn.x; hp.tau[P + p] = tn.y; hp.tau[2 * P + p] = tn.z;
-        hp.nd[p] = Nnew; hp.r2[p] = Rnew2; hp.madd[p] = 0;
-        hp.phi[p] = 0.0; hp.phi[P + p] = 0.0; hp.phi[2 * P + p] = 0.0;
-    }
-    hp.w[p] = 0.0; hp.w[P + p] = 0.0; hp.w[2 * P + p] = 0.0;
-}
-
-// image assembly, src/sppm2.h:658-670 (rule 0) / src/stochastic_ppm.h:743-765 (rule 1)
-__global__ void k_resolve(HpArrays hp, int pass, int64_t photon_num, int rule, double* __restrict__ image)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int P = hp.P;
-    if (i >= P) return;
-    d3 c = mk(hp.ld[i], hp.ld[P + i], hp.ld[2 * P + i]) / (double)(pass + 1);
-    if (hp.valid[i]) {
-        if (rule == 0)
-            c = c + mk(hp.flux[i], hp.flux[P + i], hp.flux[2 * P + i]) * (1.0 / (SPPM_PI * hp.r2[i] * (pass + 1) * (double)photon_num));
-        else
-            c = c + mk(hp.tau[i], hp.tau[P + i], hp.tau[2 * P + i]) * (1.0 / (SPPM_PI * hp.r2[i] * (double)((int64_t)(pass + 1) * photon_num)));
-    }
-    image[3 * (size_t)i] = c.x; image[3 * (size_t)i + 1] = c.y; image[3 * (size_t)i + 2] = c.z;
-}
-
-// get_hdr_pixel, src/hdr.h:37-45
-__device__ __host__ inline void hdr_pixel(double x, double y, double z, uint8_t* out)
-{
-    const double m0 = y > z ? y : z;
-    double d = x > m0 ? x : m0;
-    if (d <= 1e-32) { out[0] = out[1] = out[2] = out[3] = 0; return; }
-    int e;
-    const double m = frexp(d, &e);
-    d = m * 256.0 / d;
-    out[0] = (uint8_t)(int)(x * d); out[1] = (uint8_t)(int)(y * d); out[2] = (uint8_t)(int)(z * d); out[3] = (uint8_t)(e + 128);
-}
-__global__ void k_hdr_pixels(const double* __restrict__ rgb, int64_t n, uint8_t* __restrict__ out)
-{
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint8_t px[4];
-    hdr_pixel(rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2], px);
-    out[4 * i] = px[0]; out[4 * i + 1] = px[1]; out[4 * i + 2] = px[2]; out[4 * i + 3] = px[3];
-}
-
-// ---- record exchange between ranks: SoA buffer <-> packed rows of 10 doubles (key bits, 9 fields) -------
-// One wavefront per WAVE_ROWS buffer slots, in groups of 64: a first sweep counts the valid ones, ONE atomic per
-// wave reserves a contiguous run of rows (thousands of waves asking one counter per 64 slots would queue up on
-// it), a second sweep writes the rows, staged through LDS so that the row-major side is accessed with
-// consecutive lanes on consecutive doubles.
-#define WAVE_ROWS 1024
-__global__ void __launch_bounds__(256) k_pack_records(RecArrays rec, const unsigned long long* __restrict__ rec_count, double* __restrict__ rows, int64_t cap_rows,
-                               unsigned long long* __restrict__ n_out)
-{
-    __shared__ double s_row[4][64 * 10];
-    const int64_t n = min((int64_t)*rec_count, rec.cap);
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t w0 = ((int64_t)blockIdx.x * 4 + wv) * WAVE_ROWS;
-    if (w0 >= n) return;
-    int total = 0;
-    for (int g = 0; g < WAVE_ROWS / 64; g++) {
-        const int64_t i = w0 + g * 64 + lane;
-        total += __popcll(__ballot(i < n && rec.key[i] != REC_INVALID));
-    }
-    if (total == 0) return;
-    unsigned long long at = 0;
-    if (lane == 0) at = atomicAdd(n_out, (unsigned long long)total);
-    at = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(at >> 32)) << 32) |
-         (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)at);
-    for (int g = 0; g < WAVE_ROWS / 64; g++) {
-        const int64_t i = w0 + g * 64 + lane;
-        const unsigned long long key = i < n ? rec.key[i] : REC_INVALID;
-        const bool has = key != REC_INVALID;
-        const unsigned long long m = __ballot(has);
-        if (m == 0) continue;
-        const int cnt = __popcll(m);
-        if (has) {
-            double* r = s_row[wv] + 10 * __popcll(m & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
-            r[0] = __longlong_as_double((long long)key);
-#pragma unroll
-            for (int c = 0; c < 9; c++) r[1 + c] = rec.f[c * rec.cap + i];
-        }
-        __builtin_amdgcn_wave_barrier();
-        // rows at .. at+cnt-1, as far as they fit (the count is complete either way: the host reports the overflow)
-        const int64_t fit = min((int64_t)cnt, max((int64_t)0, cap_rows - (int64_t)at));
-        for (int64_t j = lane; j < fit * 10; j += 64) rows[(int64_t)at * 10 + j] = s_row[wv][j];
-        __builtin_amdgcn_wave_barrier();
-        at += (unsigned long long)cnt;
-    }
-}
-// ---- which records can matter to this rank ---------------------------------------------------------------
-// A coarse occupancy map over the bounding box of the rank's hitpoints (grown by the search radius), NEAR_DIM
-// cells per axis.  k_mark_near sets every cell that the box [pos - r, pos + r] of a valid hitpoint of the rank
-// overlaps, r = sqrt(min(r2, search r2)) at that moment.  Radii only shrink, so whenever the map is used later a
-// hitpoint can only accept records inside the box that was marked for it: a record whose cell is not set is
-// dropped when rows are appended or a batch is binned.  Coordinates clamp into the map (monotone, so "the cells a
-// box overlaps" survives the clamp).
-#define NEAR_DIM 64
-struct NearMap { const unsigned long long* bb; const uint8_t* cells; double reach; };  // bb: ordered-int doubles, min[3] max[3]
-__device__ __forceinline__ double near_undo(unsigned long long o)
-{
-    return __longlong_as_double((long long)((o >> 63) ? (o & 0x7fffffffffffffffull) : ~o));
-}
-__device__ __forceinline__ int near_coord(const unsigned long long* bb, double reach, int a, double v)
-{
-    const double lo = near_undo(bb[a]) - reach, ext = near_undo(bb[3 + a]) + reach - lo;
-    const double f = floor((v - lo) / (ext / (double)NEAR_DIM));
-    return f < 0.0 ? 0 : (f > (double)(NEAR_DIM - 1) ? NEAR_DIM - 1 : (int)f);
-}
-__device__ __forceinline__ bool near_rank(const NearMap& nm, double x, double y, double z)
-{
-    if (!(near_undo(nm.bb[0]) <= near_undo(nm.bb[3]))) return false;  // the rank has no valid hitpoint
-    const int ix = near_coord(nm.bb, nm.reach, 0, x), iy = near_coord(nm.bb, nm.reach, 1, y), iz = near_coord(nm.bb, nm.reach, 2, z);
-    return nm.cells[(iz * NEAR_DIM + iy) * NEAR_DIM + ix] != 0;
-}
-__global__ void k_mark_near(HpArrays hp, const int32_t* __restrict__ pix, int n, const unsigned long long* __restrict__ bb, double reach,
-                            double gather_r2, uint8_t* __restrict__ cells)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int p = pix[i], P = hp.P;
-    if (!hp.valid[p]) return;
-    const double r = sqrt(fmin(hp.r2[p], gather_r2)) * (1.0 + 1e-9) + 1e-9;
-    const double x = hp.pos[p], y = hp.pos[P + p], z = hp.pos[2 * P + p];
-    const int x0 = near_coord(bb, reach, 0, x - r), x1 = near_coord(bb, reach, 0, x + r);
-    const int y0 = near_coord(bb, reach, 1, y - r), y1 = near_coord(bb, reach, 1, y + r);
-    const int z0 = near_coord(bb, reach, 2, z - r), z1 = near_coord(bb, reach, 2, z + r);
-    for (int iz = z0; iz <= z1; iz++)
-        for (int iy = y0; iy <= y1; iy++)
-            for (int ix = x0; ix <= x1; ix++) cells[(iz * NEAR_DIM + iy) * NEAR_DIM + ix] = 1;
-}
-
-// nm.cells != nullptr: rows that cannot matter to this rank (near_rank) are not stored.
-__global__ void __launch_bounds__(256) k_append_records(RecArrays rec, unsigned long long* __restrict__ rec_count, const double* __restrict__ rows, int64_t n,
-                                                        int32_t* __restrict__ err, NearMap nm)
-{
-    __shared__ double s_row[4][64 * 10];
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t w0 = ((int64_t)blockIdx.x * 4 + wv) * WAVE_ROWS;
-    if (w0 >= n) return;
-    // first sweep: which rows of this wave's WAVE_ROWS matter to the rank (one bit mask per group of 64)
-    unsigned long long keep[WAVE_ROWS / 64];
-    int total = 0;
-#pragma unroll
-    for (int g = 0; g < WAVE_ROWS / 64; g++) {
-        const int64_t i = w0 + g * 64 + lane;
-        bool has = i < n;
-        if (has && nm.cells) has = near_rank(nm, rows[10 * i + 1], rows[10 * i + 2], rows[10 * i + 3]);
-        keep[g] = __ballot(has);
-        total += __popcll(keep[g]);
-    }
-    if (total == 0) return;
-    unsigned long long base = 0;
-    if (lane == 0) base = atomicAdd(rec_count, (unsigned long long)total);  // one reservation per wave
-    base = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) |
-           (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)base);
-    if ((int64_t)base + total > rec.cap) { if (lane == 0) err[0] = 1; return; }
-    // second sweep: the kept rows, staged through LDS (consecutive lanes read consecutive doubles)
-#pragma unroll
-    for (int g = 0; g < WAVE_ROWS / 64; g++) {
-        const unsigned long long m = keep[g];
-        if (m == 0) continue;
-        const int64_t g0 = w0 + g * 64;
-        const int64_t here = min((int64_t)64, n - g0);
-        for (int64_t j = lane; j < here * 10; j += 64) s_row[wv][j] = rows[g0 * 10 + j];
-        __builtin_amdgcn_wave_barrier();
-        if ((m >> lane) & 1ull) {
-            const double* r = s_row[wv] + 10 * lane;
-            const int64_t slot = (int64_t)base + __popcll(m & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
-            rec.key[slot] = (unsigned long long)__double_as_longlong(r[0]);
-#pragma unroll
-            for (int c = 0; c < 9; c++) rec.f[c * rec.cap + slot] = r[1 + c];
-        }
-        __builtin_amdgcn_wave_barrier();
-        base += (unsigned long long)__popcll(m);
-    }
-}
-
+#include "sppm_eye.hpp"
+#include "sppm_trace.hpp"
+#include "sppm_records.hpp"
+#include "sppm_gather_simple.hpp"
+#include "sppm_image.hpp"
+#include "sppm_exchange.hpp"
 #include "sppm_gather_tiles.hpp"
 
 // ================================ host side / C ABI =================================================
