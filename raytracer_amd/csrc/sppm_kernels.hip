@@ -282,7 +282,8 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
     if (n_spheres > SPPM_MAX_SPHERES_GRID) return fail(SPPM_ERR_INVALID, "sppm_create: more than 2^20 spheres");
     if (cfg->width < 1 || cfg->height < 1 || cfg->samples < 1 || cfg->supersamples < 1)
         return fail(SPPM_ERR_INVALID, "sppm_create: width, height, samples, supersamples must be >= 1");
-    if ((int64_t)cfg->width * cfg->height > (1ll << 30)) return fail(SPPM_ERR_INVALID, "sppm_create: image too large");
+    // the kernels index the SoA arrays with 32-bit integers (component * P + pixel) and name a tile of 64 hitpoints in 20 bits
+    if ((int64_t)cfg->width * cfg->height > (1ll << 26)) return fail(SPPM_ERR_INVALID, "sppm_create: more than 2^26 pixels");
     if (!(cfg->gather_radius2 > 0.0) || !(cfg->initial_radius2 > 0.0) || !(cfg->alpha > 0.0))
         return fail(SPPM_ERR_INVALID, "sppm_create: radii and alpha must be positive");
     if (cfg->update_rule != 0 && cfg->update_rule != 1) return fail(SPPM_ERR_INVALID, "sppm_create: update_rule must be 0 or 1");
