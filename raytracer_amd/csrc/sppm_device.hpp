@@ -140,6 +140,8 @@ struct DevScene {
     const int32_t* big;         // ids of the big spheres, ascending
     const uint32_t* cell_start; // [n_cells + 1]
     const int32_t* cell_items;  // sphere ids per cell, ascending
+    const double* cell_geom;    // [entries][4]: centre and radius of cell_items[k], so a test costs one level of loads less
+    const uint32_t* cell_mask;  // one bit per cell: it lists something (at most 2^18 cells: the kernels keep this in LDS)
 };
 
 __device__ __forceinline__ void sphere_test(const sppm_sphere* __restrict__ sp, int i, d3 org, d3 dir, double& best, int& id)
@@ -147,6 +149,19 @@ __device__ __forceinline__ void sphere_test(const sppm_sphere* __restrict__ sp, 
     const d3 p_o = ld3(sp[i].position) - org;
     const double b = dot(p_o, dir);
     const double D4 = b * b - dot(p_o, p_o) + sp[i].radius * sp[i].radius;
+    const double sq = sqrt(D4);
+    const double t1 = b - sq, t2 = b + sq;
+    const bool counts = !(D4 < 0.0) && !(t1 < SPPM_EPS && t2 < SPPM_EPS);
+    const double t = (t1 > SPPM_EPS) ? t1 : t2;
+    if (counts && (t < best || (t == best && i < id))) { best = t; id = i; }
+}
+
+// the same test from a cell's copy of the sphere's centre and radius
+__device__ __forceinline__ void sphere_test_geom(const double* __restrict__ g, int i, d3 org, d3 dir, double& best, int& id)
+{
+    const d3 p_o = mk(g[0], g[1], g[2]) - org;
+    const double b = dot(p_o, dir);
+    const double D4 = b * b - dot(p_o, p_o) + g[3] * g[3];
     const double sq = sqrt(D4);
     const double t1 = b - sq, t2 = b + sq;
     const bool counts = !(D4 < 0.0) && !(t1 < SPPM_EPS && t2 < SPPM_EPS);
@@ -194,8 +209,10 @@ __device__ __forceinline__ bool intersect_scene_grid(const DevScene& sc, d3 org,
 #undef SPPM_DDA_AXIS
         for (;;) {
             const uint32_t cell = (uint32_t)((cz * sc.gy + cy) * sc.gx + cx);
-            const uint32_t e = sc.cell_start[cell + 1];
-            for (uint32_t k = sc.cell_start[cell]; k < e; k++) sphere_test(sc.sp, sc.cell_items[k], org, dir, best, id);
+            if ((sc.cell_mask[cell >> 5] >> (cell & 31u)) & 1u) {  // most cells are empty: no trip to memory for those
+                const uint32_t e = sc.cell_start[cell + 1];
+                for (uint32_t k = sc.cell_start[cell]; k < e; k++) sphere_test_geom(sc.cell_geom + 4 * (size_t)k, sc.cell_items[k], org, dir, best, id);
+            }
             // step into the next cell along the ray; stop once the closest hit lies inside what has been walked
             if (nx <= ny && nx <= nz) { if (best < nx) break; cx += sx; if (cx < 0 || cx >= sc.gx) break; nx += dx; }
             else if (ny <= nz) { if (best < ny) break; cy += sy; if (cy < 0 || cy >= sc.gy) break; ny += dy; }
@@ -238,13 +255,19 @@ __device__ __forceinline__ bool intersect_scene(const DevScene& sc, d3 org, d3 d
         (sc).sp = (const sppm_sphere*)s_scene_dyn;                                                                    \
     }
 // The same in a kernel compiled for one kind of scene: with GRID == 0 the pointer is known to be an LDS
-// address from here on (LDS reads instead of flat ones in the sphere loop), with GRID == 1 nothing is staged.
+// address from here on (LDS reads instead of flat ones in the sphere loop); with GRID == 1 the grid's occupancy
+// bits are staged instead (scene_lds() bytes either way).
 #define STAGE_SCENE_T(sc, GRID)                                                                                      \
     extern __shared__ __align__(16) double s_scene_dyn[];                                                             \
     if constexpr ((GRID) == 0) {                                                                                      \
         for (int i_ = threadIdx.x; i_ < (sc).ns * 11; i_ += blockDim.x) s_scene_dyn[i_] = ((const double*)(sc).sp)[i_]; \
         __syncthreads();                                                                                              \
         (sc).sp = (const sppm_sphere*)s_scene_dyn;                                                                    \
+    } else {  /* the grid's occupancy bits */                                                                         \
+        uint32_t* m_ = (uint32_t*)s_scene_dyn;                                                                        \
+        for (int i_ = threadIdx.x; i_ < ((sc).n_cells + 31) / 32; i_ += blockDim.x) m_[i_] = (sc).cell_mask[i_];      \
+        __syncthreads();                                                                                              \
+        (sc).cell_mask = m_;                                                                                          \
     }
 
 // edupt::PinholeCamera, src/cameras.h:34-64

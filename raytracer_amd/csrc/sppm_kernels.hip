@@ -221,7 +221,7 @@ static int build_scene_grid(sppm_ctx* c, const sppm_sphere* sp, int n)
     for (;;) {
         int64_t ncells = 1;
         for (int a = 0; a < 3; a++) { dims[a] = (int)std::max<int64_t>(1, std::min<int64_t>(512, (int64_t)std::ceil((hi[a] - lo[a]) / cell))); ncells *= dims[a]; }
-        bool too_fine = ncells > (1ll << 24);
+        bool too_fine = ncells > (1ll << 18);  // the occupancy bits of the cells live in LDS (32 KB)
         for (int a = 0; a < 3; a++) if (dims[a] * cell < (hi[a] - lo[a])) too_fine = true;  // clamped to 512: the box must stay covered
         if (!too_fine) {
             const double inv = 1.0 / cell;
@@ -257,9 +257,20 @@ static int build_scene_grid(sppm_ctx* c, const sppm_sphere* sp, int n)
         }
         cell *= 1.5;
     }
-    int32_t* d_big = nullptr; uint32_t* d_start = nullptr; int32_t* d_items = nullptr;
+    const size_t ncells_final = (size_t)dims[0] * dims[1] * dims[2];
+    std::vector<uint32_t> mask((ncells_final + 31) / 32, 0u);
+    for (size_t cell = 0; cell < ncells_final; cell++) if (start[cell + 1] > start[cell]) mask[cell >> 5] |= 1u << (cell & 31);
+    std::vector<double> geom(items.size() * 4);
+    for (size_t k = 0; k < items.size(); k++) {
+        const sppm_sphere& q = sp[items[k]];
+        geom[4 * k] = q.position[0]; geom[4 * k + 1] = q.position[1]; geom[4 * k + 2] = q.position[2]; geom[4 * k + 3] = q.radius;
+    }
+    int32_t* d_big = nullptr; uint32_t* d_start = nullptr; int32_t* d_items = nullptr; uint32_t* d_mask = nullptr; double* d_geom = nullptr;
     int rc;
-    if ((rc = dev_alloc(c, &d_big, big.size(), false)) || (rc = dev_alloc(c, &d_start, start.size(), false)) || (rc = dev_alloc(c, &d_items, items.size(), false))) return rc;
+    if ((rc = dev_alloc(c, &d_big, big.size(), false)) || (rc = dev_alloc(c, &d_start, start.size(), false)) || (rc = dev_alloc(c, &d_items, items.size(), false)) ||
+        (rc = dev_alloc(c, &d_mask, mask.size(), false)) || (rc = dev_alloc(c, &d_geom, geom.size(), false))) return rc;
+    HIPCHK(hipMemcpy(d_mask, mask.data(), mask.size() * 4, hipMemcpyHostToDevice));
+    if (!geom.empty()) HIPCHK(hipMemcpy(d_geom, geom.data(), geom.size() * 8, hipMemcpyHostToDevice));
     if (!big.empty()) HIPCHK(hipMemcpy(d_big, big.data(), big.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_start, start.data(), start.size() * 4, hipMemcpyHostToDevice));
     if (!items.empty()) HIPCHK(hipMemcpy(d_items, items.data(), items.size() * 4, hipMemcpyHostToDevice));
@@ -267,7 +278,7 @@ static int build_scene_grid(sppm_ctx* c, const sppm_sphere* sp, int n)
     g.n_cells = dims[0] * dims[1] * dims[2]; g.n_big = (int)big.size(); g.gx = dims[0]; g.gy = dims[1]; g.gz = dims[2];
     for (int a = 0; a < 3; a++) g.g_lo[a] = lo[a];
     g.g_cell = cell; g.g_inv = 1.0 / cell;
-    g.big = d_big; g.cell_start = d_start; g.cell_items = d_items;
+    g.big = d_big; g.cell_start = d_start; g.cell_items = d_items; g.cell_mask = d_mask; g.cell_geom = d_geom;
     if (getenv("SPPM_DEBUG"))
         fprintf(stderr, "[sppm] scene grid: %d spheres, %zu big, %dx%dx%d cells of %.3f, %zu list entries\n", n, big.size(), dims[0], dims[1], dims[2], cell, items.size());
     return 0;
@@ -502,7 +513,7 @@ extern "C" int sppm_destroy(sppm_ctx* c)
 }
 
 static inline DevScene scene_of(const sppm_ctx* c) { return c->dscene; }
-static inline size_t scene_lds(const sppm_ctx* c) { return c->dscene.n_cells ? 0 : (size_t)c->ns * sizeof(sppm_sphere); }  // dynamic LDS of STAGE_SCENE
+static inline size_t scene_lds(const sppm_ctx* c) { return c->dscene.n_cells ? (size_t)((c->dscene.n_cells + 31) / 32) * 4 : (size_t)c->ns * sizeof(sppm_sphere); }  // dynamic LDS of STAGE_SCENE
 static inline int nblk(int64_t n, int b) { return (int)((n + b - 1) / b); }
 static inline double reach_of(const sppm_ctx* c) { return std::sqrt(c->cfg.gather_radius2) * (1.0 + 1e-9) + 1e-9; }
 // the occupancy map of the CURRENT view (valid on the context's stream once the eye pass is ordered before it)
