@@ -180,11 +180,17 @@ __device__ __forceinline__ void eye_pixel(const DevScene& sc, const EyeParams& e
 
 // One thread per pixel, one XorShift stream per (pass, image index).
 template <int GRID>
-__global__ void __launch_bounds__(256) k_eye_pass(DevScene sc, EyeParams ep, HpArrays hp, HpArrays out, unsigned long long* __restrict__ counters)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) k_eye_pass(DevScene sc, EyeParams ep, HpArrays hp, HpArrays out, unsigned long long* __restrict__ counters)
 {
     STAGE_SCENE_T(sc, GRID);
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int P = ep.W * ep.H;
+    // a wavefront takes an 8x8 block of pixels rather than 64 of one row: neighbouring eye paths resemble each
+    // other, and a wavefront waits for its longest one (which pixel a thread takes changes no result)
+    if (((ep.W | ep.H) & 7) == 0) {
+        const int tile = t >> 6, w = t & 63, tiles_x = ep.W >> 3;
+        t = ((tile / tiles_x) * 8 + (w >> 3)) * ep.W + (tile % tiles_x) * 8 + (w & 7);
+    }
     uint32_t rays = 0;
     if (t < P) {
         const int index = (ep.H - t / ep.W - 1) * ep.W + t % ep.W;
