@@ -63,119 +63,161 @@ __device__ __forceinline__ LensRng make_lens(const EyeParams& ep, int t, int ind
     return l;
 }
 
-// One pixel of an eye pass: the sy/sx/s loops of src/sppm2.h:628-643 around create_point_loop
-// (:156-315).  t = y*W + x is the pixel's place in the reference's render order.  COMMIT = false runs
-// the same paths without storing anything (used to count draws).
-template <class RNG, bool COMMIT, int GRID = SCENE_ANY>
-__device__ __forceinline__ void eye_pixel(const DevScene& sc, const EyeParams& ep, const HpArrays& hp, const HpArrays& out, int t, RNG& rng, uint32_t& rays)
+// One pixel of an eye pass: the sy/sx/s loops of src/sppm2.h:628-643 around create_point_loop (:156-315),
+// in pieces so that a kernel can either run a pixel from start to end (eye_pixel) or keep one pixel per lane in
+// flight and advance all lanes one ray at a time (k_eye_pass_refill).  t = y*W + x is the pixel's place in the
+// reference's render order.  COMMIT = false runs the same paths without storing anything (used to count draws).
+template <class RNG>
+struct EyeState {
+    RNG rng; LensRng lens;
+    d3 org, dir, weight, ld;
+    int x, y, index, sub, depth, valid;
+    bool direct, wrote;  // wrote: a hitpoint was stored for this pixel in this pass
+};
+
+template <class RNG>
+__device__ __forceinline__ void eye_pixel_begin(const EyeParams& ep, const HpArrays& hp, int t, EyeState<RNG>& e)
 {
     const int P = ep.W * ep.H;
-    const int x = t % ep.W, y = t / ep.W;
-    const int index = (ep.H - y - 1) * ep.W + x;
-    d3 ld = mk(hp.ld[index], hp.ld[P + index], hp.ld[2 * P + index]);
-    int valid = hp.valid[index];
-    bool wrote = false;  // a hitpoint was stored for this pixel in this pass
-    LensRng lens = make_lens(ep, t, index);
-    for (int sy = 0; sy < ep.supersamples; sy++)
-        for (int sx = 0; sx < ep.supersamples; sx++)
-            for (int s = 0; s < ep.samples; s++) {
-                d3 org, dir;
-                if (ep.cam.model == 1) camera_ray_lens(ep.cam, x, y, sx, sy, lens, org, dir);
-                else camera_ray(ep.cam, x, y, sx, sy, org, dir);
-                int depth = -1;
-                bool direct = true;
-                d3 weight = mk(1, 1, 1);
-                for (;;) {
-                    depth++;
-                    Hit is;
-                    rays++;
-                    if (!intersect_scene<GRID>(sc, org, dir, is)) break;
-                    const sppm_sphere* obj = &sc.sp[is.object_id];
-                    const d3 color = ld3(obj->color);
-                    const int type = obj->reflection_type;
-                    const d3 on = dot(is.normal, dir) < 0.0 ? is.normal : is.normal * -1.0;
-                    if (direct) ld = ld + had(weight, ld3(obj->emission));
-                    direct = type != SPPM_DIFFUSE;
-                    if (type == SPPM_DIFFUSE) {
-                        const d3 est = next_event_est<RNG, GRID>(sc, is, on, rng, rays);
-                        ld = ld + had(weight, est);
-                        // create or overwrite the pixel's hitpoint (src/sppm2.h:204-227)
-                        if constexpr (COMMIT) {
-                            out.pos[index] = is.position.x; out.pos[P + index] = is.position.y; out.pos[2 * P + index] = is.position.z;
-                            out.nrm[index] = is.normal.x; out.nrm[P + index] = is.normal.y; out.nrm[2 * P + index] = is.normal.z;
-                            out.w[index] = weight.x; out.w[P + index] = weight.y; out.w[2 * P + index] = weight.z;
-                            out.obj[index] = is.object_id; out.dist[index] = is.distance;
-                            wrote = true;
-                        }
-                        if (!valid) {
-                            valid = 1;
-                            if constexpr (COMMIT) {
-                                hp.r2[index] = ep.initial_r2;
-                                hp.n[index] = 0;  // the reference leaves photon_count unset (src/sppm2.h:108-116); its call site passes 0
-                                hp.flux[index] = 0.0; hp.flux[P + index] = 0.0; hp.flux[2 * P + index] = 0.0;
-                                if (hp.nd) {
-                                    hp.nd[index] = 0.0; hp.madd[index] = 0;
-                                    hp.phi[index] = 0.0; hp.phi[P + index] = 0.0; hp.phi[2 * P + index] = 0.0;
-                                    hp.tau[index] = 0.0; hp.tau[P + index] = 0.0; hp.tau[2 * P + index] = 0.0;
-                                }
-                            }
-                            // the reference's `break` leaves the switch only: fall into the roulette
-                            // block and go round again with the same ray (second direct sample)
-                            if (!ep.double_nee) goto path_done;
-                        } else
-                            goto path_done;
-                    } else if (type == SPPM_SPECULAR) {
-                        org = is.position;
-                        dir = reflect_dir(dir, is.normal);
-                        weight = had(weight, color);
-                    } else {
-                        const d3 rdir = reflect_dir(dir, is.normal);
-                        bool into; double nnt, Re; d3 tdir;
-                        org = is.position;
-                        if (!glass(dir, is.normal, on, true, into, nnt, tdir, Re)) {
-                            dir = rdir;
-                            weight = had(weight, color);
-                        } else {
-                            const double nnt2 = nnt * nnt;
-                            const double Tr = (1.0 - Re) * nnt2;
-                            const double prob = 0.25 + 0.5 * Re;
-                            rng.decision();
-                            if (rng.next01() < prob) {
-                                dir = rdir;
-                                weight = had(weight, color * Re / prob);
-                            } else {
-                                dir = tdir;
-                                weight = had(weight, color * Tr / (1.0 - prob));
-                            }
-                        }
-                    }
-                    {   // Russian roulette, src/sppm2.h:298-313
-                        double rr = max3(color);
-                        if (depth >= SPPM_KDEPTH) {
-                            rr *= ldexp(1.0, -(depth - SPPM_KDEPTH));  // std::pow(0.5, depth - MaxDepth)
-                            rng.decision();
-                            if (rng.next01() >= rr) break;
-                        } else
-                            rr = 1.0;
-                        weight = weight / rr;
-                    }
-                    if (rng.stop()) return;  // sequential-stream samplers only
-                }
-            path_done:;
+    e.x = t % ep.W; e.y = t / ep.W;
+    e.index = (ep.H - e.y - 1) * ep.W + e.x;
+    e.ld = mk(hp.ld[e.index], hp.ld[P + e.index], hp.ld[2 * P + e.index]);
+    e.valid = hp.valid[e.index];
+    e.wrote = false;
+    e.lens = make_lens(ep, t, e.index);
+    e.sub = 0;
+}
+
+// the next of the pixel's paths, in the order of the reference's loops (sy, sx, s); false when none is left
+template <class RNG>
+__device__ __forceinline__ bool eye_path_begin(const EyeParams& ep, EyeState<RNG>& e)
+{
+    const int ss = ep.supersamples, per = ep.samples;
+    if (e.sub >= per * ss * ss) return false;
+    const int sy = e.sub / (ss * per), sx = (e.sub / per) % ss;
+    if (ep.cam.model == 1) camera_ray_lens(ep.cam, e.x, e.y, sx, sy, e.lens, e.org, e.dir);
+    else camera_ray(ep.cam, e.x, e.y, sx, sy, e.org, e.dir);
+    e.sub++;
+    e.depth = -1;
+    e.direct = true;
+    e.weight = mk(1, 1, 1);
+    return true;
+}
+
+// one trip of create_point_loop's loop; false when the path has ended
+template <class RNG, bool COMMIT, int GRID>
+__device__ __forceinline__ bool eye_path_step(const DevScene& sc, const EyeParams& ep, const HpArrays& hp, const HpArrays& out, EyeState<RNG>& e, uint32_t& rays)
+{
+    const int P = ep.W * ep.H;
+    const int index = e.index;
+    e.depth++;
+    Hit is;
+    rays++;
+    if (!intersect_scene<GRID>(sc, e.org, e.dir, is)) return false;
+    const sppm_sphere* obj = &sc.sp[is.object_id];
+    const d3 color = ld3(obj->color);
+    const int type = obj->reflection_type;
+    const d3 on = dot(is.normal, e.dir) < 0.0 ? is.normal : is.normal * -1.0;
+    if (e.direct) e.ld = e.ld + had(e.weight, ld3(obj->emission));
+    e.direct = type != SPPM_DIFFUSE;
+    if (type == SPPM_DIFFUSE) {
+        const d3 est = next_event_est<RNG, GRID>(sc, is, on, e.rng, rays);
+        e.ld = e.ld + had(e.weight, est);
+        // create or overwrite the pixel's hitpoint (src/sppm2.h:204-227)
+        if constexpr (COMMIT) {
+            out.pos[index] = is.position.x; out.pos[P + index] = is.position.y; out.pos[2 * P + index] = is.position.z;
+            out.nrm[index] = is.normal.x; out.nrm[P + index] = is.normal.y; out.nrm[2 * P + index] = is.normal.z;
+            out.w[index] = e.weight.x; out.w[P + index] = e.weight.y; out.w[2 * P + index] = e.weight.z;
+            out.obj[index] = is.object_id; out.dist[index] = is.distance;
+            e.wrote = true;
+        }
+        if (e.valid) return false;
+        e.valid = 1;
+        if constexpr (COMMIT) {
+            hp.r2[index] = ep.initial_r2;
+            hp.n[index] = 0;  // the reference leaves photon_count unset (src/sppm2.h:108-116); its call site passes 0
+            hp.flux[index] = 0.0; hp.flux[P + index] = 0.0; hp.flux[2 * P + index] = 0.0;
+            if (hp.nd) {
+                hp.nd[index] = 0.0; hp.madd[index] = 0;
+                hp.phi[index] = 0.0; hp.phi[P + index] = 0.0; hp.phi[2 * P + index] = 0.0;
+                hp.tau[index] = 0.0; hp.tau[P + index] = 0.0; hp.tau[2 * P + index] = 0.0;
             }
+        }
+        // the reference's `break` leaves the switch only: fall into the roulette block and go round again
+        // with the same ray (second direct sample)
+        if (!ep.double_nee) return false;
+    } else if (type == SPPM_SPECULAR) {
+        e.org = is.position;
+        e.dir = reflect_dir(e.dir, is.normal);
+        e.weight = had(e.weight, color);
+    } else {
+        const d3 rdir = reflect_dir(e.dir, is.normal);
+        bool into; double nnt, Re; d3 tdir;
+        e.org = is.position;
+        if (!glass(e.dir, is.normal, on, true, into, nnt, tdir, Re)) {
+            e.dir = rdir;
+            e.weight = had(e.weight, color);
+        } else {
+            const double nnt2 = nnt * nnt;
+            const double Tr = (1.0 - Re) * nnt2;
+            const double prob = 0.25 + 0.5 * Re;
+            e.rng.decision();
+            if (e.rng.next01() < prob) {
+                e.dir = rdir;
+                e.weight = had(e.weight, color * Re / prob);
+            } else {
+                e.dir = tdir;
+                e.weight = had(e.weight, color * Tr / (1.0 - prob));
+            }
+        }
+    }
+    {   // Russian roulette, src/sppm2.h:298-313
+        double rr = max3(color);
+        if (e.depth >= SPPM_KDEPTH) {
+            rr *= ldexp(1.0, -(e.depth - SPPM_KDEPTH));  // std::pow(0.5, depth - MaxDepth)
+            e.rng.decision();
+            if (e.rng.next01() >= rr) return false;
+        } else
+            rr = 1.0;
+        e.weight = e.weight / rr;
+    }
+    return true;
+}
+
+template <class RNG, bool COMMIT>
+__device__ __forceinline__ void eye_pixel_end(const EyeParams& ep, const HpArrays& hp, const HpArrays& out, const EyeState<RNG>& e)
+{
     if constexpr (COMMIT) {
         // `out` is the view the NEXT gather reads (the eye pass of pass i+1 may run while the gather of pass i
         // still reads `hp`): the direct term, the valid flag, and -- where this pass stored no hitpoint -- the
         // hitpoint the pixel already had (the reference overwrites a pixel's hitpoint only on a diffuse hit)
-        out.ld[index] = ld.x; out.ld[P + index] = ld.y; out.ld[2 * P + index] = ld.z;
-        out.valid[index] = valid;
-        if (!wrote && valid) {
+        const int P = ep.W * ep.H;
+        const int index = e.index;
+        out.ld[index] = e.ld.x; out.ld[P + index] = e.ld.y; out.ld[2 * P + index] = e.ld.z;
+        out.valid[index] = e.valid;
+        if (!e.wrote && e.valid) {
             out.pos[index] = hp.pos[index]; out.pos[P + index] = hp.pos[P + index]; out.pos[2 * P + index] = hp.pos[2 * P + index];
             out.nrm[index] = hp.nrm[index]; out.nrm[P + index] = hp.nrm[P + index]; out.nrm[2 * P + index] = hp.nrm[2 * P + index];
             out.w[index] = hp.w[index]; out.w[P + index] = hp.w[P + index]; out.w[2 * P + index] = hp.w[2 * P + index];
             out.obj[index] = hp.obj[index]; out.dist[index] = hp.dist[index];
         }
     }
+}
+
+template <class RNG, bool COMMIT, int GRID = SCENE_ANY>
+__device__ __forceinline__ void eye_pixel(const DevScene& sc, const EyeParams& ep, const HpArrays& hp, const HpArrays& out, int t, RNG& rng, uint32_t& rays)
+{
+    EyeState<RNG> e;
+    e.rng = rng;
+    eye_pixel_begin(ep, hp, t, e);
+    while (eye_path_begin(ep, e))
+        for (;;) {
+            const bool go = eye_path_step<RNG, COMMIT, GRID>(sc, ep, hp, out, e, rays);
+            if (e.rng.stop()) { rng = e.rng; return; }  // sequential-stream samplers only: the pixel is abandoned
+            if (!go) break;
+        }
+    rng = e.rng;
+    eye_pixel_end<RNG, COMMIT>(ep, hp, out, e);
 }
 
 // One thread per pixel, one XorShift stream per (pass, image index).
@@ -200,6 +242,66 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
     // rays counter: one atomic per wave
     for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off);
     if ((threadIdx.x & 63) == 0 && rays) atomicAdd(&counters[0], (unsigned long long)rays);
+}
+
+// The same pass for scenes whose eye paths differ much in length (thousands of small mirrors and glass balls):
+// persistent wavefronts keep one pixel per lane in flight, all lanes advance one ray together, and a lane whose
+// pixel is done takes the next pixel of its wavefront's block of 64 (blocks come from one counter; 8x8 pixel
+// blocks where the image allows).  Which lane runs which pixel changes no result.
+template <int GRID>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) k_eye_pass_refill(DevScene sc, EyeParams ep, HpArrays hp, HpArrays out,
+                                                                                                   unsigned long long* __restrict__ next_block,
+                                                                                                   unsigned long long* __restrict__ counters)
+{
+    STAGE_SCENE_T(sc, GRID);
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const int P = ep.W * ep.H;
+    const bool blocks8 = ((ep.W | ep.H) & 7) == 0;
+    uint32_t rays = 0;
+    EyeState<XorShift> e;
+    e.rng.seed(1u); e.lens.u = nullptr; e.lens.pos = 0; e.lens.mode = 0; e.lens.xs.seed(1u);
+    e.org = mk(0, 0, 0); e.dir = mk(0, 0, 1); e.weight = mk(0, 0, 0); e.ld = mk(0, 0, 0);
+    e.x = e.y = e.index = e.sub = e.depth = e.valid = 0; e.direct = false; e.wrote = false;
+    bool active = false, exhausted = false;
+    long long blk_lo = 0, blk_hi = 0;  // wave-uniform: the unassigned rest of this wave's current block
+    for (;;) {
+        const unsigned long long need = __ballot(!active);
+        if (need != 0 && !exhausted) {
+            if (blk_lo >= blk_hi) {
+                unsigned long long base = 0;
+                if (lane == 0) base = atomicAdd(next_block, 64ull);
+                base = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) |
+                       (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)base);
+                blk_lo = (long long)base;
+                blk_hi = min((long long)base + 64, (long long)P);
+                if (blk_lo >= P) { exhausted = true; blk_lo = blk_hi = 0; }
+            }
+            const long long idx = blk_lo + __popcll(need & lt_mask);
+            if (!active && idx < blk_hi) {
+                int t = (int)idx;
+                if (blocks8) {
+                    const int tile = t >> 6, w = t & 63, tiles_x = ep.W >> 3;
+                    t = ((tile / tiles_x) * 8 + (w >> 3)) * ep.W + (tile % tiles_x) * 8 + (w & 7);
+                }
+                eye_pixel_begin(ep, hp, t, e);
+                e.rng = make_stream(ep.seed_eye, (uint64_t)ep.pass * (uint64_t)P + (uint64_t)e.index);
+                active = eye_path_begin(ep, e);
+                if (!active) eye_pixel_end<XorShift, true>(ep, hp, out, e);
+            }
+            blk_lo = min(blk_hi, blk_lo + (long long)__popcll(need));
+        }
+        if (__ballot(active) == 0) { if (exhausted) break; else continue; }
+        if (active) {
+            const bool go = eye_path_step<XorShift, true, GRID>(sc, ep, hp, out, e, rays);
+            if (!go && !eye_path_begin(ep, e)) {
+                eye_pixel_end<XorShift, true>(ep, hp, out, e);
+                active = false;
+            }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off);
+    if (lane == 0 && rays) atomicAdd(&counters[0], (unsigned long long)rays);
 }
 
 // ---- classic progressive photon mapping: the eye pass ------------------------------------------------------

@@ -96,6 +96,7 @@ struct sppm_ctx {
     unsigned long long* d_rec_count;
     unsigned long long* d_counters;  // 8: [0] rays [3] candidates [4] updates [5] selected [6] rounds [7] live tile launches
     unsigned long long* d_r2max;
+    unsigned long long* d_eye_next;  // block counter of k_eye_pass_refill
     unsigned long long* d_qmax;   // check_gather_max: the largest number of candidates any query held
     unsigned long long* d_trace_next;
     // double-buffered record buffers: the tracer fills one on its own stream while the gather consumes
@@ -437,7 +438,7 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
     if (hipHostMalloc((void**)&c->h_stat, 2 * sizeof(sppm_ctx::StatSlot), hipHostMallocDefault) != hipSuccess) { sppm_destroy(c); return fail(SPPM_ERR_HIP, "pinned host memory for the tile statistics"); }
     for (int b = 0; b < 2; b++)
         if (hipEventCreateWithFlags(&c->ev_stat[b], hipEventDisableTiming) != hipSuccess) { sppm_destroy(c); return fail(SPPM_ERR_HIP, "creating events failed"); }
-    TRY(dev_alloc(c, &c->d_counters, 24)); TRY(dev_alloc(c, &c->d_r2max, 1)); TRY(dev_alloc(c, &c->d_qmax, 1));
+    TRY(dev_alloc(c, &c->d_counters, 24)); TRY(dev_alloc(c, &c->d_r2max, 1)); TRY(dev_alloc(c, &c->d_qmax, 1)); TRY(dev_alloc(c, &c->d_eye_next, 1));
     TRY(dev_alloc(c, &c->d_stats, 1));
     {   // the image indices this rank owns (8x8 screen tiles dealt round-robin), in index order
         std::vector<int32_t> own;
@@ -738,7 +739,10 @@ static int eye_launch(sppm_ctx* c, int32_t pass, hipStream_t st)
         int rc = eye_pass_stream(c, ep);  // host-driven, on the context's stream
         if (rc) return rc;
     } else {
-        if (c->dscene.n_cells) hipLaunchKernelGGL(k_eye_pass<1>, dim3(nblk(c->P, 256)), dim3(256), scene_lds(c), st, scene_of(c), ep, c->hp, c->view[nv], c->d_counters);
+        if (c->dscene.n_cells) {  // large scenes: persistent wavefronts, lanes refilled (three waves per SIMD on every CU)
+            HIPCHK(hipMemsetAsync(c->d_eye_next, 0, sizeof(unsigned long long), st));
+            hipLaunchKernelGGL(k_eye_pass_refill<1>, dim3(std::min(nblk(c->P, 256), 256 * 3)), dim3(256), scene_lds(c), st, scene_of(c), ep, c->hp, c->view[nv], c->d_eye_next, c->d_counters);
+        }
         else hipLaunchKernelGGL(k_eye_pass<0>, dim3(nblk(c->P, 256)), dim3(256), scene_lds(c), st, scene_of(c), ep, c->hp, c->view[nv], c->d_counters);
         HIPCHK(hipGetLastError());
     }
