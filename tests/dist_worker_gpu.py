@@ -15,6 +15,24 @@ def main():
     out_dir, exchange, ownership = sys.argv[1], sys.argv[2], int(sys.argv[3])
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.cuda.set_device(0)
+    if exchange == "nccl1":  # ONE rank over RCCL: the collectives, streams and buffers of the all-gather flow on the real backend
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        from raytracer_amd.parallel import ShardedSppm
+        W, H, M_rank, passes = 96, 64, 24000, 3
+        job = ShardedSppm(W, H, photons_per_rank=M_rank, rank=0, world=1)
+        job.exchange, job.replicated_trace = "allgather", False   # a world of one still exchanges with itself
+        job.batch_photons = 8192
+        job.total_passes = passes
+        for i in range(passes):
+            job.step(i)
+        job.ctx.check()
+        img = job.image * job.ctx.owned_mask().to(job.image.dtype).unsqueeze(1)
+        dist.all_reduce(img, op=dist.ReduceOp.SUM)
+        hp = job.ctx.hitpoints()
+        np.savez(os.path.join(out_dir, "rank0.npz"), image=img.cpu().numpy(), n=hp["n"], r2=hp["r2"], flux=hp["flux"], mask=job.ctx.owned_mask().cpu().numpy())
+        job.close()
+        dist.destroy_process_group()
+        return
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from raytracer_amd.parallel import ShardedPpm, ShardedSppm
     W, H, M_rank, passes = 96, 64, 24000, 3

@@ -80,3 +80,22 @@ def test_two_ranks_classic_ppm_equal_one_gpu(tmp_path):
         for k in ("n", "r2", "flux"):
             a, b = np.ascontiguousarray(g[k]), np.ascontiguousarray(ref[k])
             assert (a.view(np.uint64) == b.view(np.uint64)).all() if a.dtype.kind == "f" else (a == b).all(), k
+
+
+def test_allgather_flow_over_rccl_with_one_rank(tmp_path):
+    """The exchange of ShardedSppm on the real backend: a process group of ONE rank over RCCL (all a one-GPU box allows)
+    runs the pipelined flow -- block traced ahead, packed rows, counts and records all-gathered on the side stream,
+    append, gather, masked all-reduce of the image -- and must reproduce the plain single-GPU passes bit for bit."""
+    W, H, M, passes = 96, 64, 24000, 3
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29800 + os.getpid() % 1000), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "tests", "dist_worker_gpu.py"), str(tmp_path), "nccl1", "1"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=150)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    ref_img, ref = _single(W, H, M, passes)
+    g = np.load(tmp_path / "rank0.npz")
+    assert g["mask"].all()
+    assert (g["image"].view(np.uint64) == ref_img.view(np.uint64)).all()
+    for k in ("n", "r2", "flux"):
+        a, b = np.ascontiguousarray(g[k]), np.ascontiguousarray(ref[k])
+        assert (a.view(np.uint64) == b.view(np.uint64)).all() if a.dtype.kind == "f" else (a == b).all(), k
