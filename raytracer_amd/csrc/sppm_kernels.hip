@@ -52,6 +52,7 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
         if (e_ != hipSuccess) return fail(SPPM_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
+#define NBUF 3
 struct sppm_ctx {
     sppm_config cfg;
     int device;
@@ -99,19 +100,22 @@ struct sppm_ctx {
     unsigned long long* d_eye_next;  // block counter of k_eye_pass_refill
     unsigned long long* d_qmax;   // check_gather_max: the largest number of candidates any query held
     unsigned long long* d_trace_next;
-    // double-buffered record buffers: the tracer fills one on its own stream while the gather consumes
-    // the other.  rec_u / d_rec_count / d_trace_next above always alias buffer `cur`.
-    RecArrays rec_buf[2]; unsigned long long* d_rec_count_buf[2]; unsigned long long* d_trace_next_buf[2];
+    // A ring of NBUF record buffers, each with a tracer stream of its own: the gather consumes the current one while
+    // the next two are traced and binned.  A tracer launch lasts as long as its longest photon path (a few thousand
+    // bounces inside the glass ball: 3-6 ms whatever the GPU could do meanwhile), so consecutive launches must be
+    // able to overlap -- on one stream they alone would set the pass time.
+    // rec_u / d_rec_count / d_trace_next above always alias buffer `cur`.
+    RecArrays rec_buf[NBUF]; unsigned long long* d_rec_count_buf[NBUF]; unsigned long long* d_trace_next_buf[NBUF];
     int cur;
-    hipStream_t trace_stream;
-    hipEvent_t ev_traced[2], ev_free[2];
+    hipStream_t tstream[NBUF];
+    hipEvent_t ev_traced[NBUF], ev_free[NBUF];
     struct { int valid, buf, pass; int64_t first, count; } pre;  // a batch traced ahead of its photon_pass call
     int prefetch;
     int32_t* d_err;                  // 4
     uint32_t *d_cell_cnt, *d_cell_start, *d_cursor, *d_block_sum, *d_total, *d_rec_bucket;  // alias bins[cur]
     // One set of binning tables and sorted records per record buffer: a batch is binned on the tracer's
     // stream right after it was traced, while the gather of the batch before it still runs.
-    struct BinSet { RecArrays rec_s; uint32_t *rec_bucket, *cell_cnt, *cell_start, *cursor, *block_sum, *total; TileGrid g; int binned; } bins[2];
+    struct BinSet { RecArrays rec_s; uint32_t *rec_bucket, *cell_cnt, *cell_start, *cursor, *block_sum, *total; TileGrid g; int binned; } bins[NBUF];
     // Tile statistics travel to the host one batch late (pinned slots, no stream sync in steady state):
     // they only size the grid and balance the load, never change a result.
     struct StatSlot { TileStats hs; unsigned long long bbq[6]; unsigned long long cnt[24]; };
@@ -146,7 +150,7 @@ static int grow(sppm_ctx* c, T** p, int64_t* cap, int64_t need)
 {
     if (*cap >= need) return 0;
     HIPCHK(hipStreamSynchronize(c->stream));
-    if (c->trace_stream) HIPCHK(hipStreamSynchronize(c->trace_stream));
+    for (int b = 0; b < NBUF; b++) if (c->tstream[b]) HIPCHK(hipStreamSynchronize(c->tstream[b]));
     if (*p) hipFree(*p);
     *p = nullptr; *cap = 0;
     void* q = nullptr;
@@ -331,7 +335,7 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
     c->rec_first = c->rec_end = 0;
     c->photons_applied = 0;
     c->ns = n_spheres;
-    c->trace_stream = nullptr; for (int b = 0; b < 2; b++) { c->ev_traced[b] = nullptr; c->ev_free[b] = nullptr; }
+    for (int b = 0; b < NBUF; b++) { c->tstream[b] = nullptr; c->ev_traced[b] = nullptr; c->ev_free[b] = nullptr; }
     c->eye_stream = nullptr; c->ev_eye_done = c->ev_eye_go = nullptr; c->d_order_v[0] = c->d_order_v[1] = nullptr; c->d_hp_bb_v[0] = c->d_hp_bb_v[1] = nullptr;
     c->tap_cap = 0; c->d_tap_key = nullptr; c->d_tap_pix = nullptr; c->d_tap_n = nullptr;
     c->sampler = cfg->sampler; c->eye_eng.seed(cfg->seed_eye); c->lens_eng.seed(cfg->seed_lens); c->d_u_lens = nullptr; c->u_lens_cap = 0;
@@ -399,7 +403,7 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
     // a rank of a multi-GPU run keeps the records near its hitpoints out of tile_stride x as many photons
     const int64_t cap = env_i64("SPPM_RECORD_CAP", c->batch_photons * ((c->gather_mode && c->tile_stride == 1) ? 4 : 8));
     c->rec_u.cap = cap;
-    for (int b = 0; b < 2; b++) {
+    for (int b = 0; b < NBUF; b++) {
         c->rec_buf[b].cap = cap;
         TRY(dev_alloc(c, &c->rec_buf[b].key, (size_t)cap, false)); TRY(dev_alloc(c, &c->rec_buf[b].f, 9 * (size_t)cap, false));
         TRY(dev_alloc(c, &c->d_rec_count_buf[b], 1)); TRY(dev_alloc(c, &c->d_trace_next_buf[b], 1));
@@ -410,8 +414,9 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
     if (c->sampler == 1) {
         c->prefetch = 0;  // a pass's photon stream offsets exist only once its photon pass has begun
     }
-    if (hipStreamCreateWithFlags(&c->trace_stream, hipStreamNonBlocking) != hipSuccess) { sppm_destroy(c); return fail(SPPM_ERR_HIP, "creating the trace stream failed"); }
-    for (int b = 0; b < 2; b++)
+    for (int b = 0; b < NBUF; b++)
+        if (hipStreamCreateWithFlags(&c->tstream[b], hipStreamNonBlocking) != hipSuccess) { sppm_destroy(c); return fail(SPPM_ERR_HIP, "creating the trace streams failed"); }
+    for (int b = 0; b < NBUF; b++)
         if (hipEventCreateWithFlags(&c->ev_traced[b], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_free[b], hipEventDisableTiming) != hipSuccess) {
             sppm_destroy(c); return fail(SPPM_ERR_HIP, "creating events failed");
         }
@@ -420,7 +425,7 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
     while ((int64_t)nb < cap / 2 && nb < (1u << 24)) nb <<= 1;
     c->n_buckets = nb;
     if (c->gather_mode) nb = (uint32_t)((c->table_cap + SCAN_BLOCK) / SCAN_BLOCK * SCAN_BLOCK);
-    for (int b = 0; b < (c->gather_mode ? 2 : 1); b++) {
+    for (int b = 0; b < (c->gather_mode ? NBUF : 1); b++) {
         sppm_ctx::BinSet& B = c->bins[b];
         B.rec_s.cap = cap; B.binned = 0;
         TRY(dev_alloc(c, &B.rec_s.key, (size_t)cap, false)); TRY(dev_alloc(c, &B.rec_s.f, 9 * (size_t)cap, false));
@@ -428,7 +433,7 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
         TRY(dev_alloc(c, &B.cell_cnt, (size_t)nb)); TRY(dev_alloc(c, &B.cell_start, (size_t)nb + 1)); TRY(dev_alloc(c, &B.cursor, (size_t)nb));
         TRY(dev_alloc(c, &B.block_sum, (size_t)nb / SCAN_BLOCK + 1)); TRY(dev_alloc(c, &B.total, 1));
     }
-    if (!c->gather_mode) c->bins[1] = c->bins[0];
+    if (!c->gather_mode) for (int b = 1; b < NBUF; b++) c->bins[b] = c->bins[0];
     c->h_rows_n = nullptr; c->ev_rows = nullptr; c->rows_pending = 0; c->rows_cap = 0;
     TRY(dev_alloc(c, &c->d_rows_n, 1));
     if (hipHostMalloc((void**)&c->h_rows_n, sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess || hipEventCreateWithFlags(&c->ev_rows, hipEventDisableTiming) != hipSuccess) {
@@ -490,13 +495,13 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
 extern "C" int sppm_destroy(sppm_ctx* c)
 {
     if (!c) return SPPM_OK;
-    if (c->trace_stream) hipStreamSynchronize(c->trace_stream);
+    for (int b = 0; b < NBUF; b++) if (c->tstream[b]) hipStreamSynchronize(c->tstream[b]);
     if (c->eye_stream) { hipStreamSynchronize(c->eye_stream); hipStreamDestroy(c->eye_stream); }
     if (c->ev_eye_done) hipEventDestroy(c->ev_eye_done);
     if (c->ev_eye_go) hipEventDestroy(c->ev_eye_go);
     hipStreamSynchronize(c->stream);
-    for (int b = 0; b < 2; b++) { if (c->ev_traced[b]) hipEventDestroy(c->ev_traced[b]); if (c->ev_free[b]) hipEventDestroy(c->ev_free[b]); }
-    if (c->trace_stream) hipStreamDestroy(c->trace_stream);
+    for (int b = 0; b < NBUF; b++) { if (c->ev_traced[b]) hipEventDestroy(c->ev_traced[b]); if (c->ev_free[b]) hipEventDestroy(c->ev_free[b]); }
+    for (int b = 0; b < NBUF; b++) if (c->tstream[b]) hipStreamDestroy(c->tstream[b]);
     for (auto& e : c->ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (auto& e : c->ev_trace) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (void* p : c->allocs) hipFree(p);
@@ -877,7 +882,7 @@ extern "C" int sppm_trace(sppm_ctx* c, int32_t pass, int64_t first, int64_t coun
         c->rec_first = first; c->rec_end = first + count;
         return SPPM_OK;
     }
-    if (c->pre.valid && c->pre.buf == c->cur) set_cur(c, 1 - c->cur);  // keep away from a batch traced ahead
+    if (c->pre.valid && c->pre.buf == c->cur) set_cur(c, (c->cur + 1) % NBUF);  // keep away from a batch traced ahead
     int rc = trace_into(c, c->cur, pass, first, count, c->stream);
     if (rc) return rc;
     if (c->rec_end == c->rec_first) { c->rec_first = first; c->rec_end = first + count; }
@@ -896,14 +901,14 @@ extern "C" int sppm_look_ahead(sppm_ctx* c, int32_t pass, int64_t first, int64_t
     if (c->sampler == 1 || count == 0) return SPPM_OK;  // the sequential reference stream cannot run ahead
     int rc = discard_prefetch(c);
     if (rc) return rc;
-    const int nb = 1 - c->cur;
+    const int nb = (c->cur + 1) % NBUF;
     // the other buffer is free once everything enqueued on the context's stream so far has run
     HIPCHK(hipEventRecord(c->ev_free[nb], c->stream));
-    HIPCHK(hipStreamWaitEvent(c->trace_stream, c->ev_free[nb], 0));
-    HIPCHK(hipMemsetAsync(c->d_rec_count_buf[nb], 0, sizeof(unsigned long long), c->trace_stream));
-    rc = trace_into(c, nb, pass, first, count, c->trace_stream);
+    HIPCHK(hipStreamWaitEvent(c->tstream[nb], c->ev_free[nb], 0));
+    HIPCHK(hipMemsetAsync(c->d_rec_count_buf[nb], 0, sizeof(unsigned long long), c->tstream[nb]));
+    rc = trace_into(c, nb, pass, first, count, c->tstream[nb]);
     if (rc) return rc;
-    HIPCHK(hipEventRecord(c->ev_traced[nb], c->trace_stream));
+    HIPCHK(hipEventRecord(c->ev_traced[nb], c->tstream[nb]));
     c->pre.valid = 1; c->pre.buf = nb; c->pre.pass = pass; c->pre.first = first; c->pre.count = count;
     if (pass == c->last_eye_pass + 1) { rc = eye_prefetch(c, pass); if (rc) return rc; }
     return SPPM_OK;
@@ -919,8 +924,8 @@ extern "C" int sppm_look_ahead_rows(sppm_ctx* c, int32_t pass, int64_t first, in
     c->rows_pending = 0;
     int rc = sppm_look_ahead(c, pass, first, count);
     if (rc) return rc;
-    hipStream_t ts = c->trace_stream;
-    const int nb = count > 0 ? c->pre.buf : 1 - c->cur;
+    const int nb = count > 0 ? c->pre.buf : (c->cur + 1) % NBUF;
+    hipStream_t ts = c->tstream[nb];
     HIPCHK(hipMemsetAsync(c->d_rows_n, 0, sizeof(unsigned long long), ts));
     if (count > 0) {
         hipLaunchKernelGGL(k_pack_records, dim3(nblk(c->rec_buf[nb].cap, 4 * WAVE_ROWS)), dim3(256), 0, ts, c->rec_buf[nb], c->d_rec_count_buf[nb], d_rows, cap_rows, c->d_rows_n);
@@ -1311,7 +1316,7 @@ static int discard_prefetch(sppm_ctx* c)
 {
     if (!c->pre.valid) return 0;
     const int b = c->pre.buf;
-    HIPCHK(hipStreamSynchronize(c->trace_stream));
+    HIPCHK(hipStreamSynchronize(c->tstream[b]));
     HIPCHK(hipMemsetAsync(c->d_rec_count_buf[b], 0, sizeof(unsigned long long), c->stream));
     HIPCHK(hipEventRecord(c->ev_free[b], c->stream));
     c->bins[b].binned = 0;
@@ -1352,15 +1357,15 @@ extern "C" int sppm_photon_pass(sppm_ctx* c, int32_t pass, int64_t first, int64_
         rc = discard_prefetch(c);
         if (rc) return rc;
         b = c->cur;
-        HIPCHK(hipStreamWaitEvent(c->trace_stream, c->ev_free[b], 0));
-        rc = trace_into(c, b, pass, first, n, c->trace_stream);
+        HIPCHK(hipStreamWaitEvent(c->tstream[b], c->ev_free[b], 0));
+        rc = trace_into(c, b, pass, first, n, c->tstream[b]);
         if (rc) return rc;
-        if (c->gather_mode && c->n_owned > 0) { rc = bin_into(c, b, grid_for(c, first, n), c->trace_stream); if (rc) return rc; }
-        HIPCHK(hipEventRecord(c->ev_traced[b], c->trace_stream));
+        if (c->gather_mode && c->n_owned > 0) { rc = bin_into(c, b, grid_for(c, first, n), c->tstream[b]); if (rc) return rc; }
+        HIPCHK(hipEventRecord(c->ev_traced[b], c->tstream[b]));
     }
     for (int64_t done = 0; done < count;) {
         // trace ahead into the other buffer
-        const int nb = 1 - b;
+        const int nb = (b + 1) % NBUF;
         int64_t nn = 0; int npass = pass; int64_t nfirst = first + done + n;
         bool next_call = false;  // the batch traced ahead belongs to the call expected after this one
         if (done + n < count) nn = std::min(batch_size(c, c->photons_applied + (uint64_t)n), count - done - n);
@@ -1377,11 +1382,11 @@ extern "C" int sppm_photon_pass(sppm_ctx* c, int32_t pass, int64_t first, int64_
             if (rc) return rc;
         }
         if (nn > 0) {
-            HIPCHK(hipStreamWaitEvent(c->trace_stream, c->ev_free[nb], 0));
-            rc = trace_into(c, nb, npass, nfirst, nn, c->trace_stream);
+            HIPCHK(hipStreamWaitEvent(c->tstream[nb], c->ev_free[nb], 0));
+            rc = trace_into(c, nb, npass, nfirst, nn, c->tstream[nb]);
             if (rc) return rc;
-            if (c->gather_mode && c->n_owned > 0) { rc = bin_into(c, nb, grid_for(c, nfirst, nn), c->trace_stream); if (rc) return rc; }
-            HIPCHK(hipEventRecord(c->ev_traced[nb], c->trace_stream));
+            if (c->gather_mode && c->n_owned > 0) { rc = bin_into(c, nb, grid_for(c, nfirst, nn), c->tstream[nb]); if (rc) return rc; }
+            HIPCHK(hipEventRecord(c->ev_traced[nb], c->tstream[nb]));
         }
         // gather batch b
         HIPCHK(hipStreamWaitEvent(c->stream, c->ev_traced[b], 0));
@@ -1501,7 +1506,7 @@ extern "C" int sppm_check(sppm_ctx* c)
 {
     if (!c) return fail(SPPM_ERR_INVALID, "sppm_check: null context");
     int32_t err[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    HIPCHK(hipStreamSynchronize(c->trace_stream));
+    for (int b = 0; b < NBUF; b++) HIPCHK(hipStreamSynchronize(c->tstream[b]));
     HIPCHK(hipMemcpyAsync(err, c->d_err, sizeof err, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     int rc = resolve_events(c);
@@ -1678,7 +1683,7 @@ extern "C" int sppm_counters(sppm_ctx* c, uint64_t h_out[16])
 {
     if (!c || !h_out) return fail(SPPM_ERR_INVALID, "sppm_counters: null argument");
     unsigned long long d[8], qmax = 0;
-    HIPCHK(hipStreamSynchronize(c->trace_stream));
+    for (int b = 0; b < NBUF; b++) HIPCHK(hipStreamSynchronize(c->tstream[b]));
     HIPCHK(hipMemcpyAsync(d, c->d_counters, sizeof d, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(&qmax, c->d_qmax, sizeof qmax, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
