@@ -109,7 +109,7 @@ struct sppm_ctx {
     int cur;
     hipStream_t tstream[NBUF];
     hipEvent_t ev_traced[NBUF], ev_free[NBUF];
-    struct { int valid, buf, pass; int64_t first, count; } pre;  // a batch traced ahead of its photon_pass call
+    struct Pre { int valid, buf, pass; int64_t first, count; } pre, pre2;  // batches traced ahead of their photon_pass call: the next one, and (steady state) the one after
     int prefetch;
     int32_t* d_err;                  // 4
     uint32_t *d_cell_cnt, *d_cell_start, *d_cursor, *d_block_sum, *d_total, *d_rec_bucket;  // alias bins[cur]
@@ -409,7 +409,7 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
         TRY(dev_alloc(c, &c->d_rec_count_buf[b], 1)); TRY(dev_alloc(c, &c->d_trace_next_buf[b], 1));
     }
     c->cur = 0; c->rec_u = c->rec_buf[0]; c->d_rec_count = c->d_rec_count_buf[0]; c->d_trace_next = c->d_trace_next_buf[0];  // bins[] aliases: set_cur below, once they exist
-    c->pre.valid = 0;
+    c->pre.valid = 0; c->pre2.valid = 0;
     c->prefetch = (int)env_i64("SPPM_PREFETCH", 1);
     if (c->sampler == 1) {
         c->prefetch = 0;  // a pass's photon stream offsets exist only once its photon pass has begun
@@ -867,12 +867,15 @@ static int trace_into(sppm_ctx* c, int b, int32_t pass, int64_t first, int64_t c
     return 0;
 }
 
+static int discard_prefetch(sppm_ctx* c);
+
 extern "C" int sppm_trace(sppm_ctx* c, int32_t pass, int64_t first, int64_t count)
 {
     if (!c || pass < 0 || first < 0 || count < 0) return fail(SPPM_ERR_INVALID, "sppm_trace: bad argument");
     if (c->cfg.photons_per_pass > 0 && first + count > c->cfg.photons_per_pass)
         return fail(SPPM_ERR_INVALID, "sppm_trace: photon range exceeds photons_per_pass");
     if (count == 0) return SPPM_OK;
+    if (c->pre2.valid) { int rc2 = discard_prefetch(c); if (rc2) return rc2; }
     if (c->pre.valid && c->pre.pass == pass && c->pre.first == first && c->pre.count == count && c->rec_end == c->rec_first) {
         // traced ahead (sppm_look_ahead): order it before what follows and make its buffer the current one
         HIPCHK(hipStreamWaitEvent(c->stream, c->ev_traced[c->pre.buf], 0));
@@ -1314,14 +1317,28 @@ static int64_t batch_size(const sppm_ctx* c, uint64_t applied)
 // drop a batch that was traced ahead but is not the one now asked for
 static int discard_prefetch(sppm_ctx* c)
 {
-    if (!c->pre.valid) return 0;
-    const int b = c->pre.buf;
-    HIPCHK(hipStreamSynchronize(c->tstream[b]));
-    HIPCHK(hipMemsetAsync(c->d_rec_count_buf[b], 0, sizeof(unsigned long long), c->stream));
-    HIPCHK(hipEventRecord(c->ev_free[b], c->stream));
-    c->bins[b].binned = 0;
-    c->photons_traced -= (uint64_t)c->pre.count;
-    c->pre.valid = 0;
+    for (sppm_ctx::Pre* q : {&c->pre, &c->pre2}) {
+        if (!q->valid) continue;
+        const int b = q->buf;
+        HIPCHK(hipStreamSynchronize(c->tstream[b]));
+        HIPCHK(hipMemsetAsync(c->d_rec_count_buf[b], 0, sizeof(unsigned long long), c->stream));
+        HIPCHK(hipEventRecord(c->ev_free[b], c->stream));
+        c->bins[b].binned = 0;
+        c->photons_traced -= (uint64_t)q->count;
+        q->valid = 0;
+    }
+    return 0;
+}
+
+// trace and bin photons [first, first+count) of `pass` into ring buffer `buf` on that buffer's stream, once the gather
+// that last used the buffer is done
+static int launch_ahead(sppm_ctx* c, int buf, int32_t pass, int64_t first, int64_t count)
+{
+    HIPCHK(hipStreamWaitEvent(c->tstream[buf], c->ev_free[buf], 0));
+    int rc = trace_into(c, buf, pass, first, count, c->tstream[buf]);
+    if (rc) return rc;
+    if (c->gather_mode && c->n_owned > 0) { rc = bin_into(c, buf, grid_for(c, first, count), c->tstream[buf]); if (rc) return rc; }
+    HIPCHK(hipEventRecord(c->ev_traced[buf], c->tstream[buf]));
     return 0;
 }
 
@@ -1352,17 +1369,15 @@ extern "C" int sppm_photon_pass(sppm_ctx* c, int32_t pass, int64_t first, int64_
     int b;
     if (c->pre.valid && c->pre.pass == pass && c->pre.first == first && c->pre.count == n) {
         b = c->pre.buf;
-        c->pre.valid = 0;
+        c->pre = c->pre2; c->pre2.valid = 0;
     } else {
         rc = discard_prefetch(c);
         if (rc) return rc;
         b = c->cur;
-        HIPCHK(hipStreamWaitEvent(c->tstream[b], c->ev_free[b], 0));
-        rc = trace_into(c, b, pass, first, n, c->tstream[b]);
+        rc = launch_ahead(c, b, pass, first, n);
         if (rc) return rc;
-        if (c->gather_mode && c->n_owned > 0) { rc = bin_into(c, b, grid_for(c, first, n), c->tstream[b]); if (rc) return rc; }
-        HIPCHK(hipEventRecord(c->ev_traced[b], c->tstream[b]));
     }
+    const bool single = n == count;  // the whole call is one batch (the steady state of a long render)
     for (int64_t done = 0; done < count;) {
         // trace ahead into the other buffer
         const int nb = (b + 1) % NBUF;
@@ -1381,12 +1396,24 @@ extern "C" int sppm_photon_pass(sppm_ctx* c, int32_t pass, int64_t first, int64_
             rc = eye_prefetch(c, pass + 1);
             if (rc) return rc;
         }
-        if (nn > 0) {
-            HIPCHK(hipStreamWaitEvent(c->tstream[nb], c->ev_free[nb], 0));
-            rc = trace_into(c, nb, npass, nfirst, nn, c->tstream[nb]);
-            if (rc) return rc;
-            if (c->gather_mode && c->n_owned > 0) { rc = bin_into(c, nb, grid_for(c, nfirst, nn), c->tstream[nb]); if (rc) return rc; }
-            HIPCHK(hipEventRecord(c->ev_traced[nb], c->tstream[nb]));
+        bool have = false;  // the batch wanted in buffer nb was traced during an earlier call
+        if (c->pre.valid) {
+            have = nn > 0 && c->pre.buf == nb && c->pre.pass == npass && c->pre.first == nfirst && c->pre.count == nn;
+            if (!have) { rc = discard_prefetch(c); if (rc) return rc; }
+        }
+        if (nn > 0 && !have) { rc = launch_ahead(c, nb, npass, nfirst, nn); if (rc) return rc; }
+        // Steady state (every call one batch of the same size): the batch after the next as well.  A tracer launch lasts as
+        // long as its longest photon path, often longer than a pass; started two calls ahead it is never waited for.
+        if (next_call && single && !c->pre2.valid) {
+            int p2 = npass; int64_t f2 = nfirst, n2 = nn;
+            if (c->algo == 1) { f2 = nfirst + nn; n2 = std::min(nn, c->cfg.photons_per_pass - f2); }
+            else p2 = npass + 1;
+            if (n2 > 0) {
+                const int nb2 = (b + 2) % NBUF;
+                rc = launch_ahead(c, nb2, p2, f2, n2);
+                if (rc) return rc;
+                c->pre2.valid = 1; c->pre2.buf = nb2; c->pre2.pass = p2; c->pre2.first = f2; c->pre2.count = n2;
+            }
         }
         // gather batch b
         HIPCHK(hipStreamWaitEvent(c->stream, c->ev_traced[b], 0));
@@ -1397,6 +1424,7 @@ extern "C" int sppm_photon_pass(sppm_ctx* c, int32_t pass, int64_t first, int64_
         HIPCHK(hipEventRecord(c->ev_free[b], c->stream));
         done += n;
         if (next_call) { c->pre.valid = 1; c->pre.buf = nb; c->pre.pass = npass; c->pre.first = nfirst; c->pre.count = nn; }
+        else if (have) { c->pre = c->pre2; c->pre2.valid = 0; }  // consumed within this call
         b = nb; n = nn;
     }
     return SPPM_OK;
