@@ -214,12 +214,12 @@ __global__ void __launch_bounds__(1024) k_tile_hist(const uint8_t* __restrict__ 
 }
 
 // records per cell summed over the slabs of the batch (what the plan's estimates read)
-__global__ void k_cell_totals(const uint32_t* __restrict__ cell_cnt, int ncells, int S, uint32_t* __restrict__ cell_tot)
+__global__ void k_cell_totals(const uint32_t* __restrict__ cell_start, int ncells, int S, uint32_t* __restrict__ cell_tot)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= ncells) return;
     uint32_t t = 0;
-    for (int s = 0; s < S; s++) t += cell_cnt[(size_t)s * ncells + c];
+    for (int s = 0; s < S; s++) { const size_t b = (size_t)s * ncells + c; t += cell_start[b + 1] - cell_start[b]; }
     cell_tot[c] = t;
 }
 

@@ -1000,7 +1000,7 @@ static int run_scan(sppm_ctx* c, const sppm_ctx::BinSet& B, uint32_t n_padded, h
 {
     hipLaunchKernelGGL(k_scan_blocks, dim3(n_padded / SCAN_BLOCK), dim3(SCAN_BLOCK), 0, st, B.cell_cnt, B.cell_start, B.block_sum);
     hipLaunchKernelGGL(k_scan_tops, dim3(1), dim3(SCAN_BLOCK), 0, st, B.block_sum, (int)(n_padded / SCAN_BLOCK), B.total, records_acc);
-    hipLaunchKernelGGL(k_scan_add, dim3(n_padded / SCAN_BLOCK), dim3(SCAN_BLOCK), 0, st, B.cell_start, B.block_sum, B.cursor, (size_t)n_padded, B.total);
+    hipLaunchKernelGGL(k_scan_add, dim3(n_padded / SCAN_BLOCK), dim3(SCAN_BLOCK), 0, st, B.cell_start, B.block_sum, B.cursor, (size_t)n_padded, B.total, B.cell_cnt);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1159,7 +1159,7 @@ static int bin_into(sppm_ctx* c, int b, const TileGrid& g, hipStream_t st, bool 
     sppm_ctx::BinSet& B = c->bins[b];
     const uint32_t n_table = (uint32_t)((int64_t)g.S * g.ncells);
     const uint32_t n_padded = (n_table + SCAN_BLOCK - 1) / SCAN_BLOCK * SCAN_BLOCK;
-    HIPCHK(hipMemsetAsync(B.cell_cnt, 0, sizeof(uint32_t) * n_padded, st));
+    // B.cell_cnt is all zero here: allocated so, and every scan clears what it has read (k_scan_add)
     // drop_far: only where the current view's occupancy map is final on this stream (not for batches binned ahead)
     hipLaunchKernelGGL(k_bin_count, dim3(2048), dim3(256), 0, st, c->rec_buf[b], c->d_rec_count_buf[b], g, B.cell_cnt, B.rec_bucket, c->d_err,
                        near_map(c, drop_far));
@@ -1211,7 +1211,7 @@ static int gather_tiles(sppm_ctx* c)
     const double thr_d = c->est_per_photon > 0.0 ? std::max(256.0, mean_est * c->split_factor) : 4.0e9;
     const uint32_t split_thr = (uint32_t)std::min(4.0e9, thr_d);
     HIPCHK(hipMemsetAsync(c->d_item_q, 0, sizeof(unsigned int) * (2 + ITEM_CLASSES), st));
-    hipLaunchKernelGGL(k_cell_totals, dim3(nblk(g.ncells, 256)), dim3(256), 0, st, BS.cell_cnt, g.ncells, g.S, c->d_cell_tot);
+    hipLaunchKernelGGL(k_cell_totals, dim3(nblk(g.ncells, 256)), dim3(256), 0, st, BS.cell_start, g.ncells, g.S, c->d_cell_tot);
     hipLaunchKernelGGL(k_sat_axis, dim3(nblk(g.ny * g.nz, 64)), dim3(64), 0, st, c->d_cell_tot, g.nx, g.ny, g.nz, 0);
     hipLaunchKernelGGL(k_sat_axis, dim3(nblk(g.nx * g.nz, 64)), dim3(64), 0, st, c->d_cell_tot, g.nx, g.ny, g.nz, 1);
     hipLaunchKernelGGL(k_sat_axis, dim3(nblk(g.nx * g.ny, 64)), dim3(64), 0, st, c->d_cell_tot, g.nx, g.ny, g.nz, 2);

@@ -76,13 +76,16 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_tops(uint32_t* __restrict__
     }
     if (tid == 0) { *total_out = carry; if (records_acc) atomicAdd(records_acc, (unsigned long long)carry); }
 }
+// ...and clears the counts the scan has consumed, so that the next batch finds them zero without a memset of the
+// whole table (tens of MB per batch, on a GPU whose SIMDs the gather holds)
 __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_add(uint32_t* __restrict__ out, const uint32_t* __restrict__ block_sum, uint32_t* __restrict__ cursor,
-                                                         size_t n, const uint32_t* __restrict__ total)
+                                                         size_t n, const uint32_t* __restrict__ total, uint32_t* __restrict__ counts)
 {
     const size_t i = (size_t)blockIdx.x * SCAN_BLOCK + threadIdx.x;
     const uint32_t v = out[i] + block_sum[blockIdx.x];
     out[i] = v;
     cursor[i] = v;
+    counts[i] = 0u;
     if (i == n - 1) out[n] = *total;
 }
 __global__ void k_grid_scatter(RecArrays src, RecArrays dst, const unsigned long long* __restrict__ rec_count,
