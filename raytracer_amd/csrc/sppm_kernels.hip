@@ -846,9 +846,12 @@ static int trace_into(sppm_ctx* c, int b, int32_t pass, int64_t first, int64_t c
     TraceParams tp;
     tp.pass = pass; tp.first = first; tp.count = count;
     tp.photons_per_pass = c->cfg.photons_per_pass; tp.seed_photon = c->cfg.seed_photon; tp.flux_scale = c->flux_scale; tp.rec_cap = c->rec_buf[b].cap;
-    // persistent waves: enough to fill the chip (4 waves per SIMD), never more than the photons need
+    // persistent wavefronts that take photons from one counter, never more than the photons need
     HIPCHK(hipMemsetAsync(c->d_trace_next_buf[b], 0, sizeof(unsigned long long), st));
-    const int trace_blocks = (int)std::min<int64_t>(nblk(count, 256), env_i64("SPPM_TRACE_BLOCKS", 256 * 4));
+    // A launch lasts about as long as its longest photon path whatever it is given (3-6 ms from 64 workgroups to 1024,
+    // measured), and launches overlap each other and the gather: on the 10-sphere scene 128 workgroups do the work and
+    // leave the SIMDs to the gather (+2-3 % photons/s); the grid walk of a large scene is real work and takes them all.
+    const int trace_blocks = (int)std::min<int64_t>(nblk(count, 256), env_i64("SPPM_TRACE_BLOCKS", c->dscene.n_cells ? 256 * 4 : 128));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->timing) { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventRecord(e0, st)); }
     tp.u = nullptr; tp.u_len = 0; tp.start = nullptr; tp.consumed = nullptr; tp.ppm = c->algo;
