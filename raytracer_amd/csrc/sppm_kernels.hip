@@ -1071,9 +1071,13 @@ static int stats_launch(sppm_ctx* c)
     TileParams tp;
     memset(&tp, 0, sizeof tp);
     tp.gather_r2 = c->cfg.gather_radius2; tp.order = c->d_order; tp.n_pix = c->n_own_pix; tp.n_owned = c->n_owned;
-    hipLaunchKernelGGL(k_tile_extent, dim3(nblk(c->n_owned, 4)), dim3(256), 0, st, c->hp, tp, c->d_ext_bin);
-    hipLaunchKernelGGL(k_tile_hist, dim3(1), dim3(1024), 0, st, c->d_ext_bin, c->est_valid ? c->d_est : (const uint32_t*)nullptr, c->n_owned, c->d_stats);
-    HIPCHK(hipGetLastError());
+    // the tiles' extents and the mean estimate move slowly once a render is under way: measured every fourth batch then
+    // (the counters below are copied every time; the slab length is derived from their differences batch by batch)
+    if (c->stat_n < 16 || (c->stat_n & 3) == 0) {
+        hipLaunchKernelGGL(k_tile_extent, dim3(nblk(c->n_owned, 4)), dim3(256), 0, st, c->hp, tp, c->d_ext_bin);
+        hipLaunchKernelGGL(k_tile_hist, dim3(1), dim3(1024), 0, st, c->d_ext_bin, c->est_valid ? c->d_est : (const uint32_t*)nullptr, c->n_owned, c->d_stats);
+        HIPCHK(hipGetLastError());
+    }
     sppm_ctx::StatSlot* slot = c->h_stat + c->stat_w;
     HIPCHK(hipMemcpyAsync(&slot->hs, c->d_stats, sizeof slot->hs, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(slot->bbq, c->d_hp_bb, sizeof slot->bbq, hipMemcpyDeviceToHost, st));
