@@ -55,6 +55,39 @@ def cpu_baseline(width, height, photons, seconds_target=12.0, table=None):
                       f"{done} photons in {t_ph:.1f} s, {upd} hitpoint updates ({upd / t_ph:.3g} updates/s)"}
 
 
+def reference_check(photons=20000):
+    """The compiled, unmodified reference (oracle/_ref, built by oracle/Makefile from /root/reference where that exists)
+    beside the port on a workload the reference can run: its eye pass searches the hitpoint list linearly for every
+    pixel (src/sppm2.h:213-226), which is quadratic in the pixel count, so 1920x1080 is out of its reach; at 320x240
+    the photon pass of both is timed on the same photons of pass 0.  None if the binary is not there."""
+    import re
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_driver_320x240")
+    if not os.path.exists(exe):
+        return None
+    with tempfile.TemporaryDirectory() as tmp:
+        r = subprocess.run([exe, tmp, str(photons), "1", "0", "25.0", "10000"], env=dict(os.environ, REF_TIMING="1"),
+                           capture_output=True, text=True, timeout=300)
+    m = re.search(r"eye_s ([0-9.]+) kd_s ([0-9.]+) photons (\d+) photon_s ([0-9.]+)", r.stderr)
+    if r.returncode != 0 or not m:
+        return {"error": (r.stderr or "")[-200:]}
+    import oracle_lib as ol
+    from raytracer_amd.scene import CORNELL_SPHERES
+    par = ol.make_params(320, 240, sampler=1, math=1, photons_per_pass=photons)
+    orc = ol.Oracle(par, ol.make_spheres(CORNELL_SPHERES))
+    orc.eye_pass(0)
+    t0 = time.perf_counter()
+    orc.photon_pass(0, photons, first=0)
+    t_port = time.perf_counter() - t0
+    orc.close()
+    return {"workload": f"320x240, pass 0, {photons} photons, r^2 25, K 10000, one core each",
+            "reference_photons_per_s": photons / float(m.group(4)), "port_photons_per_s": photons / t_port,
+            "reference_eye_pass_s": float(m.group(1)), "reference_kd_build_s": float(m.group(2)),
+            "note": "reference = oracle/_ref/ref_driver_320x240 (the unmodified headers compiled with g++ -O2); its eye pass "
+                    "is quadratic in the pixel count (linear search of the hitpoint list per pixel), so it cannot run 1920x1080"}
+
+
 def cpu_baseline_ppm(width, height, photons, r2, seconds_target=12.0):
     """Classic PPM on the host: the oracle's hitpoint list + kd build, then a bounded number of photons."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -325,6 +358,8 @@ def main():
             out["roofline_trace"]["note"] = "rank 0; rays cast by photon tracing; the flop figure prices a ray at the Cornell scene's 219 flop (a grid walk tests fewer spheres per ray than brute force, so this is not a flop count for this scene)"
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(W, H, M, table=table)
+            if args.spheres <= 0:
+                out["cpu_baseline"]["reference_check"] = reference_check()
         print(json.dumps(out), flush=True)
     job.close()
     if world > 1:

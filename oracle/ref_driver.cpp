@@ -20,6 +20,7 @@
 
 #include <algorithm>
 #include <array>
+#include <chrono>
 #include <climits>
 #include <cmath>
 #include <cstdint>
@@ -58,10 +59,15 @@ using edupt::Intersection;
 using edupt::Ray;
 
 static std::string g_out;
+// REF_TIMING=1: time the reference's own code (eye pass, kd-tree build, photon pass) and write no vectors; used by
+// bench.py's cpu_baseline.reference_check with the 320x240 build (the eye pass is quadratic in the pixel count: 1080p is out of reach)
+static bool g_timing = false;
+static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 template <typename T>
 static void dump(const std::string& name, const std::vector<T>& v)
 {
+    if (g_timing) return;
     std::string path = g_out + "/" + name;
     FILE* f = fopen(path.c_str(), "wb");
     if (!f) { perror(path.c_str()); exit(2); }
@@ -84,6 +90,7 @@ int main(int argc, char** argv)
         return 2;
     }
     g_out = argv[1];
+    g_timing = getenv("REF_TIMING") != nullptr;
     const int photon_num = atoi(argv[2]);
     const int passes = atoi(argv[3]);
     const int traced = atoi(argv[4]);
@@ -218,6 +225,7 @@ int main(int argc, char** argv)
 
     for (int pass = 0; pass < passes; pass++) {
         const size_t n_before = point_map.Size();
+        const double t_eye0 = now_s();
         for (int y = 0; y < H; y++)
             for (int x = 0; x < W; x++) {
                 const int image_index = (H - y - 1) * W + x;
@@ -226,6 +234,7 @@ int main(int argc, char** argv)
                         for (int s = 0; s < samples; s++)
                             sppm.create_point_loop(aperture > 0.0 ? dof.get_ray(x, y, sx, sy) : sppm.camera.get_ray(x, y, sx, sy), &eye_sampler, &point_map, image_index);
             }
+        const double t_eye = now_s() - t_eye0;
         {   // B1: the constructor leaves photon_count unset; its call site passes 0 (src/sppm2.h:208)
             auto& pts = point_map.GetData();
             for (size_t k = n_before; k < pts.size(); k++) {
@@ -233,7 +242,7 @@ int main(int argc, char** argv)
                 pts[k].accumulated_flux = Color();
             }
         }
-        {   // (4) hitpoint records and (5) direct term after this eye pass, by pixel index
+        if (!g_timing) {   // (4) hitpoint records and (5) direct term after this eye pass, by pixel index
             std::vector<int32_t> hp_i(2 * (size_t)P, -1);
             std::vector<double> hp_f(13 * (size_t)P, 0.0), ld;
             for (auto& p : point_map.GetData()) {
@@ -258,7 +267,9 @@ int main(int argc, char** argv)
             dump("eye_words_pass" + std::to_string(pass) + ".bin", w1);
         }
 
+        const double t_kd0 = now_s();
         point_map.CreateKDtree();
+        const double t_kd = now_s() - t_kd0;
 
         {   // photon pass = update_photons (src/sppm2.h:527-558) minus its progress printing
             g_seed_counter = seed_photon + pass;
@@ -268,6 +279,7 @@ int main(int argc, char** argv)
             for (auto& p : pts) prev[p.index] = p.photon_count;
             std::vector<int32_t> words_per_photon, acc_off{0}, acc_pix, acc_cnt;
             const int ntr = std::min(traced, photon_num);
+            const double t_ph0 = now_s();
             for (int i = 0; i < photon_num; i++) {
                 if (i < ntr) {
                     std::mt19937 before = ph_sampler.engine_;
@@ -288,6 +300,8 @@ int main(int argc, char** argv)
                     sppm.create_photon(edupt::spheres[0], ph_sampler, &point_map, gather_r2, gather_k);
                 }
             }
+            if (g_timing)
+                fprintf(stderr, "[ref-timing] pass %d eye_s %.6f kd_s %.6f photons %d photon_s %.6f\n", pass, t_eye, t_kd, photon_num, now_s() - t_ph0);
             dump("ph_words_pass" + std::to_string(pass) + ".bin", words_per_photon);
             dump("ph_acc_off_pass" + std::to_string(pass) + ".bin", acc_off);
             dump("ph_acc_pix_pass" + std::to_string(pass) + ".bin", acc_pix);
@@ -319,8 +333,8 @@ int main(int argc, char** argv)
         fprintf(stderr, "[ref] pass %d done, %zu hitpoints\n", pass, point_map.Size());
     }
     // (9) the reference's own writers on the final image (src/hdr.h:48, src/ppm.h:22)
-    photonmap::utility::save_hdr_file(g_out + "/final.hdr", image.data(), W, H);
-    edupt::save_ppm_file(g_out + "/final.ppm", image.data(), W, H);
+    if (!g_timing) photonmap::utility::save_hdr_file(g_out + "/final.hdr", image.data(), W, H);
+    if (!g_timing) edupt::save_ppm_file(g_out + "/final.ppm", image.data(), W, H);
     std::cout.rdbuf(cout_buf);
     return 0;
 }
