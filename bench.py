@@ -349,7 +349,7 @@ def main():
                                  "frac": tflops / 78.6, "launches": int(t_launch), "avg_launch_ms": t_ns / 1e6 / t_launch,
                                  "rays_per_launch": p_rays / t_launch,
                                  "note": "rank 0; 219 flop per ray (20 x 9 spheres + 19, SURVEY 8d) x rays cast by photon tracing; overlapped with the gather"}
-        out["roofline"]["traffic"] = measured_traffic(W, H, M, args.steps)
+        out["roofline"]["traffic"] = measured_traffic(W, H, M, args.steps) if world == 1 else None  # the PMC passes were made at N = 1
         bw = measured_stream_bandwidth(torch)
         out["roofline"]["peak_measured"] = bw
         out["roofline"]["frac_of_measured"] = achieved / bw
