@@ -119,7 +119,7 @@ __device__ __forceinline__ unsigned long long spread3(unsigned long long x)  // 
 }
 // Morton code, MORTON_BITS bits per axis over the bounding box (ties keep pixel order: the sort is stable);
 // invalid hitpoints sort last
-#define MORTON_BITS 12
+#define MORTON_BITS 10
 #define MORTON_MAX ((double)((1 << MORTON_BITS) - 1))
 __global__ void k_hp_sortkeys(HpArrays hp, const int32_t* __restrict__ pix, int n, const unsigned long long* __restrict__ bb,
                               unsigned long long* __restrict__ keys)
