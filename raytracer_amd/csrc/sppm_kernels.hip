@@ -180,6 +180,18 @@ static void host_cross(const double* a, const double* b, double* o)
     o[0] = (a[1] * b[2]) - (a[2] * b[1]); o[1] = (a[2] * b[0]) - (a[0] * b[2]); o[2] = (a[0] * b[1]) - (a[1] * b[0]);
 }
 
+// A context lives on the HIP device that was current in sppm_create (include/sppm_hip.h): its buffers, streams and
+// events belong to that device, so a call made with another device current is refused rather than left to fault.
+static int ctx_device(const sppm_ctx* c, const char* who)
+{
+    int d = -1;
+    if (hipGetDevice(&d) != hipSuccess) return fail(SPPM_ERR_HIP, std::string(who) + ": hipGetDevice failed");
+    if (d != c->device)
+        return fail(SPPM_ERR_STATE, std::string(who) + ": the context belongs to HIP device " + std::to_string(c->device) + " but device " + std::to_string(d) + " is current");
+    return 0;
+}
+#define CTX_DEVICE(c, who) do { int rc_dev_ = ctx_device((c), who); if (rc_dev_) return rc_dev_; } while (0)
+
 extern "C" const char* sppm_last_error(void) { return g_err.c_str(); }
 
 extern "C" int sppm_device_count(void)
@@ -461,15 +473,15 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
         TRY(dev_alloc(c, &c->d_hp_keys, own.size(), false)); TRY(dev_alloc(c, &c->d_hp_keys_out, own.size(), false));
         TRY(dev_alloc(c, &c->d_hp_bb_v[0], 6)); TRY(dev_alloc(c, &c->d_hp_bb_v[1], 6)); c->d_hp_bb = c->d_hp_bb_v[0];
         TRY(dev_alloc(c, &c->d_near_v[0], (size_t)NEAR_DIM * NEAR_DIM * NEAR_DIM)); TRY(dev_alloc(c, &c->d_near_v[1], (size_t)NEAR_DIM * NEAR_DIM * NEAR_DIM)); c->d_near = c->d_near_v[0];
-        TRY(dev_alloc(c, &c->d_own_mask, P));
-        {
-            std::vector<uint8_t> mask(P, 0);
-            for (int32_t p : own) mask[(size_t)p] = 1;
-            if (hipMemcpy(c->d_own_mask, mask.data(), P, hipMemcpyHostToDevice) != hipSuccess) { sppm_destroy(c); return fail(SPPM_ERR_HIP, "copying the ownership mask failed"); }
-        }
-        if (!own.empty() && hipMemcpy(c->d_own_pix, own.data(), own.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+        TRY(dev_alloc(c, &c->d_own_mask, P, false));  // every byte is written by the upload below
+        std::vector<uint8_t> mask(P, 0);  // lives until the stream synchronisation at the end of sppm_create
+        for (int32_t p : own) mask[(size_t)p] = 1;
+        // both uploads on the context's stream, like everything else here (a caller's non-blocking stream is not ordered with the null stream)
+        if (P > 0 && hipMemcpyAsync(c->d_own_mask, mask.data(), P, hipMemcpyHostToDevice, c->stream) != hipSuccess) { sppm_destroy(c); return fail(SPPM_ERR_HIP, "copying the ownership mask failed"); }
+        if (!own.empty() && hipMemcpyAsync(c->d_own_pix, own.data(), own.size() * 4, hipMemcpyHostToDevice, c->stream) != hipSuccess) {
             sppm_destroy(c); return fail(SPPM_ERR_HIP, "copying the pixel list failed");
         }
+        if (hipStreamSynchronize(c->stream) != hipSuccess) { sppm_destroy(c); return fail(SPPM_ERR_HIP, "sppm_create: stream sync failed"); }
         c->sort_tmp_bytes = 0; c->d_sort_tmp = nullptr; c->order_valid = 0;
         TRY(dev_alloc(c, &c->d_est, (size_t)c->n_owned + 1)); TRY(dev_alloc(c, &c->d_items, (size_t)c->n_owned * 64 + 64, false)); TRY(dev_alloc(c, &c->d_items_raw, (size_t)c->n_owned * 64 + 64, false));
         TRY(dev_alloc(c, &c->d_cell_tot, (size_t)c->table_cap / 4 + 1)); TRY(dev_alloc(c, &c->d_item_q, 2 + ITEM_CLASSES)); TRY(dev_alloc(c, &c->d_n_pieces, (size_t)c->n_owned + 1)); TRY(dev_alloc(c, &c->d_est_sum, 1)); TRY(dev_alloc(c, &c->d_ext_bin, (size_t)c->n_owned + 1)); c->est_valid = 0;
@@ -532,6 +544,7 @@ static inline NearMap near_map(const sppm_ctx* c, bool use)
 extern "C" int sppm_camera_rays(sppm_ctx* c, int32_t sx, int32_t sy, double* d_rays)
 {
     if (!c || !d_rays) return fail(SPPM_ERR_INVALID, "sppm_camera_rays: null argument");
+    CTX_DEVICE(c, "sppm_camera_rays");
     const double* lens_u = nullptr;
     if (c->cam.model == 1 && c->sampler == 1) {  // a fresh lens engine: draws 2i, 2i+1 belong to ray i of the render order
         std::mt19937 eng(c->cfg.seed_lens);
@@ -552,6 +565,7 @@ extern "C" int sppm_camera_rays(sppm_ctx* c, int32_t sx, int32_t sy, double* d_r
 extern "C" int sppm_intersect(sppm_ctx* c, const double* d_rays, int64_t n, int32_t* d_id, double* d_hit)
 {
     if (!c || n < 0 || (n > 0 && (!d_rays || !d_id || !d_hit))) return fail(SPPM_ERR_INVALID, "sppm_intersect: bad argument");
+    CTX_DEVICE(c, "sppm_intersect");
     if (n == 0) return SPPM_OK;
     hipLaunchKernelGGL(k_intersect, dim3(nblk(n, 256)), dim3(256), scene_lds(c), c->stream, scene_of(c), d_rays, n, d_id, d_hit);
     HIPCHK(hipGetLastError());
@@ -753,8 +767,9 @@ static int eye_launch(sppm_ctx* c, int32_t pass, hipStream_t st)
     }
     if (c->gather_mode && c->n_own_pix > 0) {
         // re-form the gather tiles: sort this rank's hitpoints along a Morton curve of their positions
-        unsigned long long init[6] = {~0ull, ~0ull, ~0ull, 0ull, 0ull, 0ull};
-        HIPCHK(hipMemcpyAsync(c->d_hp_bb_v[nv], init, sizeof init, hipMemcpyHostToDevice, st));
+        // bounding box seed: min slots all ones, max slots zero (ordered-int doubles); two memsets, nothing host-sourced
+        HIPCHK(hipMemsetAsync(c->d_hp_bb_v[nv], 0xFF, 3 * sizeof(unsigned long long), st));
+        HIPCHK(hipMemsetAsync(c->d_hp_bb_v[nv] + 3, 0x00, 3 * sizeof(unsigned long long), st));
         hipLaunchKernelGGL(k_hp_bbox, dim3(std::min(nblk(c->n_own_pix, 256), 512)), dim3(256), 0, st, c->view[nv], c->d_own_pix, c->n_own_pix, c->d_hp_bb_v[nv]);
         hipLaunchKernelGGL(k_hp_sortkeys, dim3(nblk(c->n_own_pix, 256)), dim3(256), 0, st, c->view[nv], c->d_own_pix, c->n_own_pix, c->d_hp_bb_v[nv], c->d_hp_keys);
         HIPCHK(hipGetLastError());
@@ -775,7 +790,8 @@ static int eye_launch(sppm_ctx* c, int32_t pass, hipStream_t st)
             if (n > 0) hipLaunchKernelGGL(k_mask_from_list, dim3(nblk(n, 256)), dim3(256), 0, st, c->d_own_pix, n, c->d_own_mask);
             c->n_own_pix = n; c->n_owned = (n + 63) / 64; c->own_pending = 0;
             if (n > 0) {  // the bounding box of what this rank keeps
-                HIPCHK(hipMemcpyAsync(c->d_hp_bb_v[nv], init, sizeof init, hipMemcpyHostToDevice, st));
+                HIPCHK(hipMemsetAsync(c->d_hp_bb_v[nv], 0xFF, 3 * sizeof(unsigned long long), st));
+                HIPCHK(hipMemsetAsync(c->d_hp_bb_v[nv] + 3, 0x00, 3 * sizeof(unsigned long long), st));
                 hipLaunchKernelGGL(k_hp_bbox, dim3(std::min(nblk(n, 256), 512)), dim3(256), 0, st, c->view[nv], c->d_own_pix, n, c->d_hp_bb_v[nv]);
             }
             HIPCHK(hipGetLastError());
@@ -814,6 +830,7 @@ static int eye_prefetch(sppm_ctx* c, int32_t pass)
 extern "C" int sppm_eye_pass(sppm_ctx* c, int32_t pass)
 {
     if (!c || pass < 0) return fail(SPPM_ERR_INVALID, "sppm_eye_pass: bad argument");
+    CTX_DEVICE(c, "sppm_eye_pass");
     if (c->algo == 1 && pass != 0) return fail(SPPM_ERR_INVALID, "sppm_eye_pass: classic progressive photon mapping traces its hitpoints once (pass 0)");
     if (c->pre_eye.valid) {
         c->pre_eye.valid = 0;
@@ -875,6 +892,7 @@ static int discard_prefetch(sppm_ctx* c);
 extern "C" int sppm_trace(sppm_ctx* c, int32_t pass, int64_t first, int64_t count)
 {
     if (!c || pass < 0 || first < 0 || count < 0) return fail(SPPM_ERR_INVALID, "sppm_trace: bad argument");
+    CTX_DEVICE(c, "sppm_trace");
     if (c->cfg.photons_per_pass > 0 && first + count > c->cfg.photons_per_pass)
         return fail(SPPM_ERR_INVALID, "sppm_trace: photon range exceeds photons_per_pass");
     if (count == 0) return SPPM_OK;
@@ -902,6 +920,7 @@ static int eye_prefetch(sppm_ctx* c, int32_t pass);
 extern "C" int sppm_look_ahead(sppm_ctx* c, int32_t pass, int64_t first, int64_t count)
 {
     if (!c || pass < 0 || first < 0 || count < 0) return fail(SPPM_ERR_INVALID, "sppm_look_ahead: bad argument");
+    CTX_DEVICE(c, "sppm_look_ahead");
     if (c->cfg.photons_per_pass > 0 && first + count > c->cfg.photons_per_pass)
         return fail(SPPM_ERR_INVALID, "sppm_look_ahead: photon range exceeds photons_per_pass");
     if (c->sampler == 1 || count == 0) return SPPM_OK;  // the sequential reference stream cannot run ahead
@@ -926,6 +945,7 @@ extern "C" int sppm_look_ahead(sppm_ctx* c, int32_t pass, int64_t first, int64_t
 extern "C" int sppm_look_ahead_rows(sppm_ctx* c, int32_t pass, int64_t first, int64_t count, double* d_rows, int64_t cap_rows)
 {
     if (!c || !d_rows || cap_rows < 0) return fail(SPPM_ERR_INVALID, "sppm_look_ahead_rows: bad argument");
+    CTX_DEVICE(c, "sppm_look_ahead_rows");
     if (c->sampler == 1) return fail(SPPM_ERR_STATE, "sppm_look_ahead_rows: the sequential reference stream cannot run ahead");
     c->rows_pending = 0;
     int rc = sppm_look_ahead(c, pass, first, count);
@@ -970,6 +990,7 @@ static int slots_in_use(sppm_ctx* c, int64_t* n)
 extern "C" int sppm_pack_records(sppm_ctx* c, double* d_rows, int64_t cap_rows, int64_t* n)
 {
     if (!c || !n || cap_rows < 0 || (cap_rows > 0 && !d_rows)) return fail(SPPM_ERR_INVALID, "sppm_pack_records: bad argument");
+    CTX_DEVICE(c, "sppm_pack_records");
     HIPCHK(hipMemsetAsync(c->d_r2max, 0, sizeof(unsigned long long), c->stream));  // reused as the row counter
     hipLaunchKernelGGL(k_pack_records, dim3(nblk(c->rec_u.cap, 4 * WAVE_ROWS)), dim3(256), 0, c->stream, c->rec_u, c->d_rec_count, d_rows, cap_rows, c->d_r2max);
     HIPCHK(hipGetLastError());
@@ -986,6 +1007,7 @@ extern "C" int sppm_pack_records(sppm_ctx* c, double* d_rows, int64_t cap_rows, 
 extern "C" int sppm_append_records(sppm_ctx* c, const double* d_rows, int64_t n, int64_t photon_first, int64_t photon_end)
 {
     if (!c || n < 0 || (n > 0 && !d_rows) || photon_first < 0 || photon_end < photon_first) return fail(SPPM_ERR_INVALID, "sppm_append_records: bad argument");
+    CTX_DEVICE(c, "sppm_append_records");
     if (photon_end > photon_first) {
         if (c->rec_end == c->rec_first) { c->rec_first = photon_first; c->rec_end = photon_end; }
         else { c->rec_first = std::min(c->rec_first, photon_first); c->rec_end = std::max(c->rec_end, photon_end); }
@@ -1304,6 +1326,7 @@ static int gather_tiles(sppm_ctx* c)
 extern "C" int sppm_gather(sppm_ctx* c)
 {
     if (!c) return fail(SPPM_ERR_INVALID, "sppm_gather: null context");
+    CTX_DEVICE(c, "sppm_gather");
     if (c->cfg.check_gather_max && c->P > 0 && c->rec_end != c->rec_first) {
         hipLaunchKernelGGL(k_count_queries, dim3(nblk(c->rec_u.cap, 256)), dim3(256), 0, c->stream, c->hp, c->rec_u, c->d_rec_count, c->cfg.gather_radius2,
                            (long long)c->cfg.gather_max, c->d_err, c->d_qmax);
@@ -1358,6 +1381,7 @@ static int launch_ahead(sppm_ctx* c, int buf, int32_t pass, int64_t first, int64
 extern "C" int sppm_photon_pass(sppm_ctx* c, int32_t pass, int64_t first, int64_t count)
 {
     if (!c || pass < 0 || first < 0 || count < 0) return fail(SPPM_ERR_INVALID, "sppm_photon_pass: bad argument");
+    CTX_DEVICE(c, "sppm_photon_pass");
     if (c->cfg.photons_per_pass > 0 && first + count > c->cfg.photons_per_pass)
         return fail(SPPM_ERR_INVALID, "sppm_photon_pass: photon range exceeds photons_per_pass");
     if (count == 0) return SPPM_OK;
@@ -1440,6 +1464,7 @@ extern "C" int sppm_photon_pass(sppm_ctx* c, int32_t pass, int64_t first, int64_
 extern "C" int sppm_end_pass(sppm_ctx* c)
 {
     if (!c) return fail(SPPM_ERR_INVALID, "sppm_end_pass: null context");
+    CTX_DEVICE(c, "sppm_end_pass");
     if (c->cfg.update_rule != 1 || c->P == 0) return SPPM_OK;
     hipLaunchKernelGGL(k_end_pass, dim3(nblk(c->P, 256)), dim3(256), 0, c->stream, c->hp, own_of(c), c->cfg.alpha);
     HIPCHK(hipGetLastError());
@@ -1449,6 +1474,7 @@ extern "C" int sppm_end_pass(sppm_ctx* c)
 extern "C" int sppm_resolve(sppm_ctx* c, int32_t pass, int64_t photon_num, double* d_image)
 {
     if (!c || !d_image || pass < 0 || photon_num < 1) return fail(SPPM_ERR_INVALID, "sppm_resolve: bad argument");
+    CTX_DEVICE(c, "sppm_resolve");
     if (c->algo == 1)
         hipLaunchKernelGGL(k_ppm_resolve, dim3(nblk(c->npix, 256)), dim3(256), 0, c->stream, c->hp, scene_of(c), c->d_hoff, c->cfg.width, c->cfg.height, photon_num,
                            (double)(c->cfg.samples * (c->cfg.supersamples * c->cfg.supersamples)), d_image);
@@ -1461,6 +1487,7 @@ extern "C" int sppm_resolve(sppm_ctx* c, int32_t pass, int64_t photon_num, doubl
 extern "C" int sppm_hdr_pixels(sppm_ctx* c, const double* d_rgb, int64_t n, uint8_t* d_rgbe)
 {
     if (!c || n < 0 || (n > 0 && (!d_rgb || !d_rgbe))) return fail(SPPM_ERR_INVALID, "sppm_hdr_pixels: bad argument");
+    CTX_DEVICE(c, "sppm_hdr_pixels");
     if (n == 0) return SPPM_OK;
     hipLaunchKernelGGL(k_hdr_pixels, dim3(nblk(n, 256)), dim3(256), 0, c->stream, d_rgb, n, d_rgbe);
     HIPCHK(hipGetLastError());
@@ -1540,6 +1567,7 @@ static int resolve_events(sppm_ctx* c)
 extern "C" int sppm_check(sppm_ctx* c)
 {
     if (!c) return fail(SPPM_ERR_INVALID, "sppm_check: null context");
+    CTX_DEVICE(c, "sppm_check");
     int32_t err[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int b = 0; b < NBUF; b++) HIPCHK(hipStreamSynchronize(c->tstream[b]));
     HIPCHK(hipMemcpyAsync(err, c->d_err, sizeof err, hipMemcpyDeviceToHost, c->stream));
@@ -1642,6 +1670,7 @@ extern "C" int sppm_download_records(sppm_ctx* c, uint64_t* h_key, double* h_f, 
 extern "C" int sppm_owned_mask(sppm_ctx* c, uint8_t* d_mask)
 {
     if (!c || !d_mask) return fail(SPPM_ERR_INVALID, "sppm_owned_mask: null argument");
+    CTX_DEVICE(c, "sppm_owned_mask");
     if (c->own_pending) return fail(SPPM_ERR_STATE, "sppm_owned_mask: spatial ownership is decided by the first eye pass");
     HIPCHK(hipMemcpyAsync(d_mask, c->d_own_mask, (size_t)c->P, hipMemcpyDeviceToDevice, c->stream));
     return SPPM_OK;
@@ -1650,6 +1679,7 @@ extern "C" int sppm_owned_mask(sppm_ctx* c, uint8_t* d_mask)
 extern "C" int sppm_export_owned_state(sppm_ctx* c, double* d_out)
 {
     if (!c || !d_out) return fail(SPPM_ERR_INVALID, "sppm_export_owned_state: null argument");
+    CTX_DEVICE(c, "sppm_export_owned_state");
     if (c->cfg.update_rule != 0) return fail(SPPM_ERR_STATE, "sppm_export_owned_state: update_rule 0 only");
     if (c->P == 0) return SPPM_OK;
     hipLaunchKernelGGL(k_export_state, dim3(nblk(c->P, 256)), dim3(256), 0, c->stream, c->hp, own_of(c), d_out);
@@ -1660,6 +1690,7 @@ extern "C" int sppm_export_owned_state(sppm_ctx* c, double* d_out)
 extern "C" int sppm_import_state(sppm_ctx* c, const double* d_in)
 {
     if (!c || !d_in) return fail(SPPM_ERR_INVALID, "sppm_import_state: null argument");
+    CTX_DEVICE(c, "sppm_import_state");
     if (c->cfg.update_rule != 0) return fail(SPPM_ERR_STATE, "sppm_import_state: update_rule 0 only");
     if (c->P == 0) return SPPM_OK;
     hipLaunchKernelGGL(k_import_state, dim3(nblk(c->P, 256)), dim3(256), 0, c->stream, c->hp, d_in);

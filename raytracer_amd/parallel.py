@@ -107,7 +107,7 @@ class ShardedSppm:
         with torch.cuda.stream(self._side):
             counts = exchange_counts(cnt, self.world, self.ctx.device)
             m = max(1, int(max(counts)))
-            dist.all_gather_into_tensor(self._all[buf][:self.world * m], self._rows[buf][:m])
+            all_gather_into(self._all[buf][:self.world * m], self._rows[buf][:m])
         self._next = dict(key=(i, done, n), counts=counts, m=m, buf=buf)
 
     def _photon_pass_allgather(self, i):
@@ -150,7 +150,7 @@ class ShardedSppm:
         if self.world == 1:
             return self.image
         out = self.image * self.ctx.owned_mask().to(self.image.dtype).unsqueeze(1)
-        dist.all_reduce(out, op=dist.ReduceOp.SUM)
+        all_reduce_sum(out)
         return out
 
     def close(self):
@@ -189,7 +189,7 @@ class ShardedPpm(ShardedSppm):
         import torch.distributed as dist
         if self.world > 1:
             state = self.ctx.export_owned_state()
-            dist.all_reduce(state, op=dist.ReduceOp.SUM)
+            all_reduce_sum(state)
             self.ctx.import_state(state)
         self.image = self.ctx.resolve(0, self.M * self.steps)
         return self.image
@@ -205,10 +205,49 @@ def select_by_owner(stacked, owner):
     return stacked[idx, torch.arange(stacked.shape[1], device=stacked.device)]
 
 
+# ---- collectives -------------------------------------------------------------------------------------------
+# RCCL (backend "nccl") takes device tensors as they are.  With gloo -- the backend that rehearses the N > 1 flow on
+# a box with fewer GPUs than ranks -- NO CUDA tensor enters the collective: gloo's own handling of CUDA tensors
+# between local processes was seen to stall (round 1: both ranks stuck inside all_gather_into_tensor with > 100 MB
+# messages, reproduced without this package), so device tensors are staged through pinned host memory there.
+def _host_staged(t):
+    import torch.distributed as dist
+    return t.is_cuda and dist.get_backend() == "gloo"
+
+
+def _pinned_like(t):
+    import torch
+    return torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+
+
+def all_gather_into(out, inp):
+    import torch.distributed as dist
+    if _host_staged(inp):
+        h_in, h_out = _pinned_like(inp), _pinned_like(out)
+        h_in.copy_(inp)
+        dist.all_gather_into_tensor(h_out, h_in)
+        out.copy_(h_out)
+    else:
+        dist.all_gather_into_tensor(out, inp)
+
+
+def all_reduce_sum(t):
+    import torch.distributed as dist
+    if _host_staged(t):
+        h = _pinned_like(t)
+        h.copy_(t)
+        dist.all_reduce(h, op=dist.ReduceOp.SUM)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+
+
 def exchange_counts(count, world, device):
-    """all-gather one integer per rank (works with nccl on GPU tensors and gloo on CPU tensors)."""
+    """all-gather one integer per rank"""
     import torch
     import torch.distributed as dist
+    if dist.get_backend() == "gloo":
+        device = "cpu"
     mine = torch.tensor([count], dtype=torch.int64, device=device)
     out = torch.empty((world,), dtype=torch.int64, device=device)
     dist.all_gather_into_tensor(out, mine)

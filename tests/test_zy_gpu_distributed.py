@@ -15,6 +15,16 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _run(cmd, env, timeout=150):
+    """A hang is a failure (it used to be a skip): the workers' output is part of the message.  No CUDA tensor enters
+    gloo any more -- raytracer_amd.parallel stages them through pinned host memory -- which is what stalled before."""
+    try:
+        return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+    except subprocess.TimeoutExpired as e:
+        out = (e.stdout or b"").decode(errors="replace")[-2000:] + (e.stderr or b"").decode(errors="replace")[-4000:]
+        pytest.fail(f"the two-rank run did not finish within {timeout} s:\n{out}")
+
+
 def _single(W, H, M, passes):
     ctx = sppm.SppmContext(sppm.make_config(W, H, photons_per_pass=M))
     for i in range(passes):
@@ -32,12 +42,7 @@ def test_two_ranks_equal_one_gpu(tmp_path, exchange, ownership):
     port = 29600 + os.getpid() % 1000 + (0 if exchange == "allgather" else 1) + 2 * ownership
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker_gpu.py"), str(tmp_path), exchange, str(ownership)]
-    try:
-        res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=100)
-    except subprocess.TimeoutExpired:
-        # gloo's all-gather of CUDA tensors between two local processes was seen to hang on its own on this pool
-        # (a probe without any of this repository's code, with >100 MB messages); the messages here are ~3 MB
-        pytest.skip("the gloo transport did not finish within 100 s")
+    res = _run(cmd, env)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     ref_img, ref = _single(W, H, M_rank * world, passes)
     got = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
@@ -61,10 +66,7 @@ def test_two_ranks_classic_ppm_equal_one_gpu(tmp_path):
     port = 29700 + os.getpid() % 1000
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker_gpu.py"), str(tmp_path), "ppm", "1"]
-    try:
-        res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=100)
-    except subprocess.TimeoutExpired:
-        pytest.skip("the gloo transport did not finish within 100 s")
+    res = _run(cmd, env)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     total = M_rank * world * steps
     ctx = sppm.SppmContext(sppm.make_config(W, H, supersamples=2, photons_per_pass=total, gather_radius2=5.0, initial_radius2=5.0, algorithm=1))
