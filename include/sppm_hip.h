@@ -137,6 +137,18 @@ int sppm_camera_rays(sppm_ctx* ctx, int32_t supersample_x, int32_t supersample_y
  * (distance = 1e128 and zeros on a miss). */
 int sppm_intersect(sppm_ctx* ctx, const double* d_rays, int64_t n, int32_t* d_id, double* d_hit);
 
+/* NO COUNTERPART IN THE REFERENCE.  sppm_intersect for callers that cannot allocate: code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc.  Same closest hit over the same ray batch, but without a
+ * context: the sphere table (h_spheres, a HOST array read during the call; at most 512 spheres) and a hit counter
+ * live in one file-scope device array of the library (45 312 bytes per GPU, held until the process ends), the
+ * table travels as kernel arguments, and the call consists of one memset and a few kernel launches on `stream`
+ * (a hipStream_t, NULL = the default stream): no hipMalloc / hipFree / host-sourced copy.  d_rays[n][6],
+ * d_id[n], d_hit[n][7] as for sppm_intersect; d_n_hit (device, may be NULL) receives the number of rays that hit.
+ * More than 512 spheres: SPPM_ERR_INVALID (such scenes need sppm_create, which builds a grid).  Every call on a
+ * GPU shares that GPU's array: calls that overlap on one GPU (different streams or threads) race -- serialise them. */
+int sppm_intersect_static(const sppm_sphere* h_spheres, int32_t n_spheres, const double* d_rays, int64_t n, int32_t* d_id,
+                          double* d_hit, uint64_t* d_n_hit, void* stream);
+
 /* One eye pass: the y/x/sy/sx/s loops of render() calling create_point_loop (src/sppm2.h:625-646,
  * :156-315) including next_event_est (src/radiance.h:29-70).  One XorShift stream per
  * (pass, image index).  Replaces CreateKDtree too (src/sppm2.h:649): nothing is built over the
