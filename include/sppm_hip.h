@@ -66,7 +66,12 @@ typedef struct sppm_config {
                                 validation mode, O(records x hitpoints)); sppm_check() then reports
                                 SPPM_ERR_OVERFLOW if any exceeded K, sppm_counters [14] the largest. */
     int32_t update_rule;     /* 0: per-photon shrink, src/sppm2.h:391-421 (default, the live SPPM)
-                                1: per-pass (N, tau) update, src/stochastic_ppm.h:721-741 */
+                                1: per-pass (N, tau) update, src/stochastic_ppm.h:721-741: photons deposit into
+                                   per-hitpoint accumulators (:439-456) kept in 64-bit fixed point (exact integer
+                                   sums: independent of the order and of the number of GPUs), sppm_end_pass applies
+                                   the update.  Over several GPUs every rank keeps all hitpoints, deposits the
+                                   photons it traced, and the accumulators are summed with ONE all-reduce per pass
+                                   (sppm_export_deposits / sppm_import_deposits). */
     int32_t double_nee;      /* 1 reproduces the reference's first-sight double direct sample
                                 (`break` leaves the switch, src/sppm2.h:204-227); 0 switches it off */
     uint32_t seed_eye, seed_photon;
@@ -189,8 +194,18 @@ int sppm_gather(sppm_ctx* ctx);
 int sppm_pack_records(sppm_ctx* ctx, double* d_rows, int64_t cap_rows, int64_t* n);
 int sppm_append_records(sppm_ctx* ctx, const double* d_rows, int64_t n, int64_t photon_first, int64_t photon_end);
 
-/* End-of-pass update of rule 1 (src/stochastic_ppm.h:721-741); a no-op for rule 0. */
+/* End-of-pass update of rule 1 (src/stochastic_ppm.h:721-741) from the pass's deposits, which it clears; a no-op
+ * for rule 0. */
 int sppm_end_pass(sppm_ctx* ctx);
+
+/* No counterpart in the reference (it is single-threaded): the per-pass rule between GPUs.  d_out / d_in are
+ * DEVICE arrays of 4 * sppm_hitpoint_count 64-bit integers, [4][P] = the fixed-point sums of the deposited photon
+ * flux (x, y, z; sppm_fixed_point_scale units per unit of flux) and the deposit count M of the pass so far.  A
+ * rank exports its deposits, the ranks' arrays are summed element-wise (an all-reduce; integer sums are exact,
+ * so the result does not depend on the number of ranks), the sum is imported, then sppm_end_pass.  update_rule 1. */
+int sppm_export_deposits(sppm_ctx* ctx, int64_t* d_out);
+int sppm_import_deposits(sppm_ctx* ctx, const int64_t* d_in);
+int sppm_fixed_point_scale(sppm_ctx* ctx, double* scale);
 
 /* Image assembly, src/sppm2.h:658-670: d_image[P][3] = ld/(pass+1) + flux/(pi r^2 (pass+1) photon_num). */
 int sppm_resolve(sppm_ctx* ctx, int32_t pass, int64_t photon_num, double* d_image);

@@ -35,9 +35,10 @@ __global__ void k_intersect(DevScene sc, const double* __restrict__ rays, int64_
 }
 
 struct HpArrays {
-    double *pos, *nrm, *w, *flux, *ld, *phi, *tau;  // [3][P]
+    double *pos, *nrm, *w, *flux, *ld, *tau;  // [3][P]
     double *r2, *dist, *nd;
-    int32_t *n, *obj, *valid, *madd;
+    int32_t *n, *obj, *valid;
+    long long* dep;  // per-pass rule only: [4][P] = the pass's deposits, fixed-point flux x y z and the count M (sppm_deposit.hpp)
     int P;
 };
 
@@ -137,9 +138,8 @@ __device__ __forceinline__ bool eye_path_step(const DevScene& sc, const EyeParam
             hp.r2[index] = ep.initial_r2;
             hp.n[index] = 0;  // the reference leaves photon_count unset (src/sppm2.h:108-116); its call site passes 0
             hp.flux[index] = 0.0; hp.flux[P + index] = 0.0; hp.flux[2 * P + index] = 0.0;
-            if (hp.nd) {
-                hp.nd[index] = 0.0; hp.madd[index] = 0;
-                hp.phi[index] = 0.0; hp.phi[P + index] = 0.0; hp.phi[2 * P + index] = 0.0;
+            if (hp.nd) {  // per-pass rule (the deposits of a pixel that was not valid are zero already)
+                hp.nd[index] = 0.0;
                 hp.tau[index] = 0.0; hp.tau[P + index] = 0.0; hp.tau[2 * P + index] = 0.0;
             }
         }
@@ -198,7 +198,10 @@ __device__ __forceinline__ void eye_pixel_end(const EyeParams& ep, const HpArray
         if (!e.wrote && e.valid) {
             out.pos[index] = hp.pos[index]; out.pos[P + index] = hp.pos[P + index]; out.pos[2 * P + index] = hp.pos[2 * P + index];
             out.nrm[index] = hp.nrm[index]; out.nrm[P + index] = hp.nrm[P + index]; out.nrm[2 * P + index] = hp.nrm[2 * P + index];
-            out.w[index] = hp.w[index]; out.w[P + index] = hp.w[P + index]; out.w[2 * P + index] = hp.w[2 * P + index];
+            // per-pass rule: the end of every pass zeroes the weight (src/stochastic_ppm.h:740), so a hitpoint that this
+            // pass did not renew carries none -- written here, so that this pass may run ahead of that zeroing
+            const bool keep_w = hp.nd == nullptr;
+            out.w[index] = keep_w ? hp.w[index] : 0.0; out.w[P + index] = keep_w ? hp.w[P + index] : 0.0; out.w[2 * P + index] = keep_w ? hp.w[2 * P + index] : 0.0;
             out.obj[index] = hp.obj[index]; out.dist[index] = hp.dist[index];
         }
     }

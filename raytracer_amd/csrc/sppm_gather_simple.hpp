@@ -2,6 +2,18 @@
 // Part of the single translation unit sppm_kernels.hip (included there, in order; not a stand-alone header).
 #pragma once
 
+// fixed point of the deposits: x * scale (scale a power of two chosen from the emitted flux by sppm_create: the
+// largest emitted component lands in [2^27, 2^28)), rounded to nearest-even, clamped at 2^41 (reported: err[6])
+#define FX_CLAMP 2199023255552.0
+#define FX_MAX_DEPOSITS (1ll << 21)  // per hitpoint and pass: with the clamp a sum stays below 2^62
+__device__ __forceinline__ long long fx_fix(double v, double scale, bool& clamped)
+{
+    double x = v * scale;
+    if (!(x < FX_CLAMP)) { x = FX_CLAMP; clamped = true; }
+    if (x < 0.0) x = 0.0;
+    return __double2ll_rn(x);
+}
+
 // max over valid hitpoints of min(r2, gather_r2), as an ordered-int atomic max on the bit pattern
 struct Own { const uint8_t* mask; };  // mask[p] != 0: this rank owns pixel p
 __device__ __forceinline__ bool owned(const Own& o, int p) { return o.mask[p] != 0; }
@@ -22,7 +34,7 @@ __global__ void k_r2max(HpArrays hp, Own own, double gather_r2, unsigned long lo
 
 // ---- gather: each hitpoint replays the records near it in key order ------------------------------------
 struct GatherParams {
-    Grid g; double gather_r2, alpha; int rule; Own own;
+    Grid g; double gather_r2, alpha; int rule; Own own; double fx_scale; int32_t* err;
     int unit_weight;  // classic PPM: the record's flux is applied as it is (no hitpoint weight or colour)
     uint64_t* tap_key; int32_t* tap_pix; unsigned long long* tap_n; int64_t tap_cap;
 };
@@ -59,10 +71,11 @@ __global__ void __launch_bounds__(256) k_gather(HpArrays hp, DevScene sc, RecArr
             const d3 hw = gp.unit_weight ? mk(1, 1, 1) : mk(hp.w[p], hp.w[P + p], hp.w[2 * P + p]);
             const d3 hcol = gp.unit_weight ? mk(1, 1, 1) : ld3(sc.sp[hp.obj[p]].color);
             double r2 = hp.r2[p];
-            int n = 0; double nd = 0.0; int madd = 0;
-            d3 acc;
+            int n = 0;
+            d3 acc = mk(0, 0, 0);
+            long long fx = 0, fy = 0, fz = 0, madd = 0;  // per-pass rule: fixed-point deposits (sppm_deposit.hpp)
+            bool clamped = false;
             if (gp.rule == 0) { n = hp.n[p]; acc = mk(hp.flux[p], hp.flux[P + p], hp.flux[2 * P + p]); }
-            else { madd = hp.madd[p]; acc = mk(hp.phi[p], hp.phi[P + p], hp.phi[2 * P + p]); }
             // cells overlapping the sphere of the larger of the two bounds the tests use
             const double rr = sqrt(fmin(r2, gp.gather_r2)) * (1.0 + 1e-9) + 1e-12;
             const int x0 = cell_coord(hpos.x - rr, gp.g.inv_cell), x1 = cell_coord(hpos.x + rr, gp.g.inv_cell);
@@ -114,8 +127,7 @@ __global__ void __launch_bounds__(256) k_gather(HpArrays hp, DevScene sc, RecArr
                         n++;
                         acc = (acc + had(hw, had(hcol, pf)) / SPPM_PI) * g;
                     } else {             // src/stochastic_ppm.h:449-454
-                        const d3 f = hcol / SPPM_PI;
-                        acc = acc + had(pf, f);
+                        fx += fx_fix(pf.x, gp.fx_scale, clamped); fy += fx_fix(pf.y, gp.fx_scale, clamped); fz += fx_fix(pf.z, gp.fx_scale, clamped);
                         madd++;
                     }
                     n_acc++;
@@ -129,11 +141,10 @@ __global__ void __launch_bounds__(256) k_gather(HpArrays hp, DevScene sc, RecArr
             if (gp.rule == 0) {
                 hp.r2[p] = r2; hp.n[p] = n;
                 hp.flux[p] = acc.x; hp.flux[P + p] = acc.y; hp.flux[2 * P + p] = acc.z;
-            } else {
-                hp.madd[p] = madd;
-                hp.phi[p] = acc.x; hp.phi[P + p] = acc.y; hp.phi[2 * P + p] = acc.z;
+            } else if (madd > 0) {
+                hp.dep[p] += fx; hp.dep[(size_t)P + p] += fy; hp.dep[2 * (size_t)P + p] += fz; hp.dep[3 * (size_t)P + p] += madd;
+                if (clamped) gp.err[6] = 1;
             }
-            (void)nd;
         }
     }
     for (int off = 32; off > 0; off >>= 1) { n_cand += __shfl_down(n_cand, off); n_acc += __shfl_down(n_acc, off); }

@@ -424,7 +424,7 @@ __global__ void __launch_bounds__(256) GATHER_WAVES_ATTR k_gather_tiles(HpArrays
     const unsigned long long w_start = STAMPS ? wall_clock64() : 0ull;
     d3 hpos = mk(0, 0, 0), hn = mk(0, 0, 0), hw = mk(0, 0, 0), hcol = mk(0, 0, 0), acc = mk(0, 0, 0);
     double r2 = 0.0;
-    int n = 0, madd = 0;
+    int n = 0;
     if (live) {
         hpos = mk(hp.pos[p], hp.pos[P + p], hp.pos[2 * P + p]);
         hn = mk(hp.nrm[p], hp.nrm[P + p], hp.nrm[2 * P + p]);
@@ -434,8 +434,7 @@ __global__ void __launch_bounds__(256) GATHER_WAVES_ATTR k_gather_tiles(HpArrays
             hcol = ld3(sc.sp[hp.obj[p]].color);
         }
         r2 = hp.r2[p];
-        if (tp.rule == 0) { n = hp.n[p]; acc = mk(hp.flux[p], hp.flux[P + p], hp.flux[2 * P + p]); }
-        else { madd = hp.madd[p]; acc = mk(hp.phi[p], hp.phi[P + p], hp.phi[2 * P + p]); }
+        n = hp.n[p]; acc = mk(hp.flux[p], hp.flux[P + p], hp.flux[2 * P + p]);
     }
     unsigned int c_cand = 0, c_sel = 0, c_acc = 0, c_round = 0;  // wave-uniform tallies except c_acc (per lane)
     unsigned long long c_pairs = 0;
@@ -610,25 +609,18 @@ __global__ void __launch_bounds__(256) GATHER_WAVES_ATTR k_gather_tiles(HpArrays
                     const d3 ff = mk(row[7], row[8], row[9]);
                     const double d2 = len2(dir);
                     const bool take = has && (d2 <= r2);
-                    if (tp.rule == 0) {  // src/sppm2.h:397-419
-                        if (__ballot(take) != 0ull) {
-                            const double na = n * tp.alpha;
-                            double g = (na + tp.alpha) / (na + 1.0);
-                            if (n == 0) g = 1;
-                            const d3 num = had(hw, had(hcol, ff));
-                            const d3 add = mk(dm_div_pi(num.x), dm_div_pi(num.y), dm_div_pi(num.z));  // == num / PI, bit for bit
-                            if (take) {
-                                r2 = r2 * g;
-                                n++;
-                                acc = (acc + add) * g;
-                                c_acc++;
-                            }
+                    if (__ballot(take) != 0ull) {  // src/sppm2.h:397-419
+                        const double na = n * tp.alpha;
+                        double g = (na + tp.alpha) / (na + 1.0);
+                        if (n == 0) g = 1;
+                        const d3 num = had(hw, had(hcol, ff));
+                        const d3 add = mk(dm_div_pi(num.x), dm_div_pi(num.y), dm_div_pi(num.z));  // == num / PI, bit for bit
+                        if (take) {
+                            r2 = r2 * g;
+                            n++;
+                            acc = (acc + add) * g;
+                            c_acc++;
                         }
-                    } else if (take) {   // src/stochastic_ppm.h:449-454
-                        const d3 f = hcol / SPPM_PI;
-                        acc = acc + had(ff, f);
-                        madd++;
-                        c_acc++;
                     }
                     if (tp.tap_cap > 0 && take) {
                         const unsigned long long slot = atomicAdd(tp.tap_n, 1ull);
@@ -644,13 +636,8 @@ __global__ void __launch_bounds__(256) GATHER_WAVES_ATTR k_gather_tiles(HpArrays
     }
     }  // clusters
     if (live) {
-        if (tp.rule == 0) {
-            hp.r2[p] = r2; hp.n[p] = n;
-            hp.flux[p] = acc.x; hp.flux[P + p] = acc.y; hp.flux[2 * P + p] = acc.z;
-        } else {
-            hp.madd[p] = madd;
-            hp.phi[p] = acc.x; hp.phi[P + p] = acc.y; hp.phi[2 * P + p] = acc.z;
-        }
+        hp.r2[p] = r2; hp.n[p] = n;
+        hp.flux[p] = acc.x; hp.flux[P + p] = acc.y; hp.flux[2 * P + p] = acc.z;
     }
     for (int off = 32; off > 0; off >>= 1) c_acc += __shfl_down(c_acc, off);
     if (lane == 0) {

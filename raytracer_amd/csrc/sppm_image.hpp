@@ -28,29 +28,6 @@ __global__ void k_import_state(HpArrays hp, const double* __restrict__ in)
     hp.n[h] = (int32_t)o[4];
 }
 
-// end-of-pass update of rule 1, src/stochastic_ppm.h:721-741
-__global__ void k_end_pass(HpArrays hp, Own own, double alpha)
-{
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    const int P = hp.P;
-    if (p >= P) return;
-    if (!hp.valid[p] || !owned(own, p)) return;
-    const int madd = hp.madd[p];
-    if (madd > 0) {
-        const double N = hp.nd[p], r2 = hp.r2[p];
-        const double Nnew = N + alpha * madd;
-        const double Rnew2 = r2 * Nnew / (N + madd);
-        const d3 tau = mk(hp.tau[p], hp.tau[P + p], hp.tau[2 * P + p]);
-        const d3 phi = mk(hp.phi[p], hp.phi[P + p], hp.phi[2 * P + p]);
-        const d3 w = mk(hp.w[p], hp.w[P + p], hp.w[2 * P + p]);
-        const d3 tn = (tau + had(phi, w)) * Rnew2 / r2;
-        hp.tau[p] = tn.x; hp.tau[P + p] = tn.y; hp.tau[2 * P + p] = tn.z;
-        hp.nd[p] = Nnew; hp.r2[p] = Rnew2; hp.madd[p] = 0;
-        hp.phi[p] = 0.0; hp.phi[P + p] = 0.0; hp.phi[2 * P + p] = 0.0;
-    }
-    hp.w[p] = 0.0; hp.w[P + p] = 0.0; hp.w[2 * P + p] = 0.0;
-}
-
 // image assembly, src/sppm2.h:658-670 (rule 0) / src/stochastic_ppm.h:743-765 (rule 1)
 __global__ void k_resolve(HpArrays hp, int pass, int64_t photon_num, int rule, double* __restrict__ image)
 {

@@ -42,6 +42,7 @@
 #include "sppm_image.hpp"
 #include "sppm_exchange.hpp"
 #include "sppm_gather_tiles.hpp"
+#include "sppm_deposit.hpp"
 
 // ================================ host side / C ABI =================================================
 
@@ -79,6 +80,9 @@ struct sppm_ctx {
     void* d_sort_tmp; size_t sort_tmp_bytes;
     uint32_t *d_cell_tot, *d_est, *d_items; unsigned long long* d_items_raw; unsigned int* d_item_q; uint8_t* d_n_pieces; unsigned long long* d_est_sum; uint8_t* d_ext_bin; int est_valid;  // d_item_q: [0] items [1] queue head [2..33] per cost class
     double split_factor, est_per_photon; int64_t est_range;
+    double fx_scale;          // per-pass rule: fixed point of the deposits (sppm_deposit.hpp), a power of two
+    double cell_factor_dep;   // per-pass rule: cell size of the record grid as a share of the median tile extent
+    int64_t dep_chunk;        // per-pass rule: records per work item
     int order_valid;
     sppm_sphere* d_spheres; int ns;
     DevScene dscene;   // what the kernels get: the table, and for large scenes the grid over the small spheres
@@ -345,6 +349,9 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
     c->cell_factor = 0.35;
     { const char* e = getenv("SPPM_CELL_FACTOR"); if (e && *e) c->cell_factor = atof(e); }
     c->slab_B = env_i64("SPPM_SLAB_PHOTONS", 1024);
+    c->cell_factor_dep = 0.15;
+    { const char* e = getenv("SPPM_DEP_CELL_FACTOR"); if (e && *e && atof(e) > 0.0) c->cell_factor_dep = atof(e); }
+    c->dep_chunk = std::max<int64_t>(64, env_i64("SPPM_DEP_CHUNK", 2048));
     c->rec_first = c->rec_end = 0;
     c->photons_applied = 0;
     c->ns = n_spheres;
@@ -387,6 +394,12 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
     {   // std::pow(light.radius * M_PI, 2.0), src/sppm2.h:348
         const double rp = h_spheres[0].radius * SPPM_PI;
         c->flux_scale = rp * rp;
+        // fixed point of the per-pass rule's deposits: the largest emitted flux component x scale lies in [2^27, 2^28)
+        double m = 0.0;
+        for (int k = 0; k < 3; k++) m = std::max(m, h_spheres[0].emission[k] * 4.0 * c->flux_scale);
+        int e = 0;
+        if (m > 0.0) std::frexp(m, &e);
+        c->fx_scale = m > 0.0 ? std::ldexp(1.0, 28 - e) : 1.0;
     }
     if (c->sampler == 1) {
         TRY(dev_alloc(c, &c->d_eye_cnt, (size_t)c->npix)); TRY(dev_alloc(c, &c->d_eye_off, (size_t)c->npix));
@@ -401,8 +414,8 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
     TRY(dev_alloc(c, &c->hp.r2, P)); TRY(dev_alloc(c, &c->hp.dist, P));
     TRY(dev_alloc(c, &c->hp.n, P)); TRY(dev_alloc(c, &c->hp.obj, P)); TRY(dev_alloc(c, &c->hp.valid, P));
     if (cfg->update_rule == 1) {
-        TRY(dev_alloc(c, &c->hp.phi, 3 * P)); TRY(dev_alloc(c, &c->hp.tau, 3 * P)); TRY(dev_alloc(c, &c->hp.nd, P)); TRY(dev_alloc(c, &c->hp.madd, P));
-    } else { c->hp.phi = c->hp.tau = c->hp.nd = nullptr; c->hp.madd = nullptr; }
+        TRY(dev_alloc(c, &c->hp.tau, 3 * P)); TRY(dev_alloc(c, &c->hp.nd, P)); TRY(dev_alloc(c, &c->hp.dep, 4 * P));
+    } else { c->hp.tau = c->hp.nd = nullptr; c->hp.dep = nullptr; }
     c->view[0] = c->hp; c->view[1] = c->hp; c->cur_view = 0; c->pre_eye.valid = 0; c->last_eye_pass = -1;
     TRY(dev_alloc(c, &c->view[1].pos, 3 * P)); TRY(dev_alloc(c, &c->view[1].nrm, 3 * P)); TRY(dev_alloc(c, &c->view[1].w, 3 * P));
     TRY(dev_alloc(c, &c->view[1].ld, 3 * P)); TRY(dev_alloc(c, &c->view[1].dist, P)); TRY(dev_alloc(c, &c->view[1].obj, P)); TRY(dev_alloc(c, &c->view[1].valid, P));
@@ -817,7 +830,7 @@ static void flip_view(sppm_ctx* c)
 // depend on photons.  Assumes the caller goes on with sppm_eye_pass(pass + 1); anything else drops it.
 static int eye_prefetch(sppm_ctx* c, int32_t pass)
 {
-    if (!c->prefetch || c->sampler == 1 || c->cfg.update_rule != 0 || c->pre_eye.valid || c->algo == 1) return 0;
+    if (!c->prefetch || c->sampler == 1 || c->pre_eye.valid || c->algo == 1) return 0;
     // the other view was last read by the pass before this one, whose work is all on the context's stream by now
     HIPCHK(hipEventRecord(c->ev_eye_go, c->stream));
     HIPCHK(hipStreamWaitEvent(c->eye_stream, c->ev_eye_go, 0));
@@ -1075,7 +1088,7 @@ static int gather_simple(sppm_ctx* c)
     hipLaunchKernelGGL(k_grid_scatter, dim3(2048), dim3(256), 0, st, c->rec_u, c->rec_s, c->d_rec_count, c->d_rec_bucket, c->d_cursor);
     GatherParams gp;
     gp.g = g; gp.gather_r2 = c->cfg.gather_radius2; gp.alpha = c->cfg.alpha; gp.rule = c->cfg.update_rule;
-    gp.own = own_of(c); gp.unit_weight = c->algo;
+    gp.own = own_of(c); gp.unit_weight = c->algo; gp.fx_scale = c->fx_scale; gp.err = c->d_err;
     gp.tap_key = c->d_tap_key; gp.tap_pix = c->d_tap_pix; gp.tap_n = c->d_tap_n; gp.tap_cap = c->tap_cap;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->timing) { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventRecord(e0, st)); }
@@ -1132,7 +1145,7 @@ static int stats_read(sppm_ctx* c)
         int med = 0;
         double med_frac = 1.0;
         { unsigned int acc = 0; for (int e = 0; e < 64; e++) { acc += hs.hist[e]; if (2 * acc >= hs.live_tiles) { med = e; med_frac = hs.hist[e] ? 1.0 - (double)(acc - (hs.live_tiles + 1) / 2) / (double)hs.hist[e] : 1.0; break; } } }
-        double cell = std::ldexp(1.0, med - 33) * std::exp2(med_frac) * c->cell_factor;
+        double cell = std::ldexp(1.0, med - 33) * std::exp2(med_frac) * (c->cfg.update_rule == 1 ? c->cell_factor_dep : c->cell_factor);
         double hi[3];
         // grid box: the hitpoints' bounding box (made by the eye pass) grown by the largest search radius;
         // positions outside it (a later pass may move hitpoints) fall into the border cells, on both sides alike
@@ -1155,7 +1168,7 @@ static int stats_read(sppm_ctx* c)
     // slab length: aim at ~20 in-region candidates per (tile, slab), far from the 64 of one round.  The
     // snapshot of slot r was taken when gather j-1 began, the one before it when gather j-2 began: their
     // difference is what gather j-2 did, with the slab length it used.
-    if (c->snap_prev_valid && c->gather_j >= 2 && !getenv("SPPM_SLAB_PHOTONS")) {
+    if (c->snap_prev_valid && c->gather_j >= 2 && c->cfg.update_rule == 0 && !getenv("SPPM_SLAB_PHOTONS")) {
         const double tiles_run = (double)(sl.cnt[7] - c->snap_prev[7]);
         const int64_t S = c->hist_S[(c->gather_j - 2) & 3], B = c->hist_B[(c->gather_j - 2) & 3];
         if (tiles_run > 0 && S > 0) {
@@ -1174,6 +1187,7 @@ static int stats_read(sppm_ctx* c)
 static TileGrid grid_for(const sppm_ctx* c, int64_t first, int64_t range)
 {
     int64_t B = std::max<int64_t>(64, std::min<int64_t>(c->slab_B, range));
+    if (c->cfg.update_rule == 1) B = std::max<int64_t>(1, range);  // the per-pass rule keeps no order: one slab
     int64_t S = (range + B - 1) / B;
     if (S * c->gs.ncells > c->table_cap) { S = std::max<int64_t>(1, c->table_cap / c->gs.ncells); B = (range + S - 1) / S; S = (range + B - 1) / B; }
     TileGrid g;
@@ -1323,6 +1337,61 @@ static int gather_tiles(sppm_ctx* c)
     return SPPM_OK;
 }
 
+// The per-pass rule's gather of the current record buffer (sppm_deposit.hpp): bin by cell (one slab), plan the work
+// items from the summed-area table, deposit.  Same stream discipline as gather_tiles.
+static int deposit_tiles(sppm_ctx* c)
+{
+    hipStream_t st = c->stream;
+    const int64_t range = c->rec_end - c->rec_first;
+    sppm_ctx::BinSet& BS = c->bins[c->cur];
+    if (c->n_owned == 0 || range == 0) {
+        BS.binned = 0;
+        c->gather_batches++; c->photons_applied += (uint64_t)range; c->rec_first = c->rec_end = 0;
+        HIPCHK(hipMemsetAsync(c->d_rec_count, 0, sizeof(unsigned long long), st));
+        return SPPM_OK;
+    }
+    if (!c->order_valid) return fail(SPPM_ERR_STATE, "sppm_gather: no eye pass has run on this context yet");
+    int rc = stats_read(c);
+    if (rc) return rc;
+    rc = stats_launch(c);  // for the batch after this one
+    if (rc) return rc;
+    if (!BS.binned) { rc = bin_into(c, c->cur, grid_for(c, c->rec_first, range), st, c->tile_stride > 1); if (rc) return rc; }
+    const TileGrid g = BS.g;
+    TileParams tp;
+    memset(&tp, 0, sizeof tp);
+    tp.gather_r2 = c->cfg.gather_radius2; tp.alpha = c->cfg.alpha; tp.rule = 1;
+    tp.order = c->d_order; tp.n_pix = c->n_own_pix; tp.n_owned = c->n_owned;
+    tp.tap_key = c->d_tap_key; tp.tap_pix = c->d_tap_pix; tp.tap_n = c->d_tap_n; tp.tap_cap = c->tap_cap;
+    tp.g = g;
+    tp.cluster_d = c->gs.cluster_d;
+    c->gather_j++;
+    HIPCHK(hipMemsetAsync(c->d_item_q, 0, sizeof(unsigned int) * (2 + ITEM_CLASSES), st));
+    hipLaunchKernelGGL(k_cell_totals, dim3(nblk(g.ncells, 256)), dim3(256), 0, st, BS.cell_start, g.ncells, g.S, c->d_cell_tot);
+    hipLaunchKernelGGL(k_sat_axis, dim3(nblk(g.ny * g.nz, 64)), dim3(64), 0, st, c->d_cell_tot, g.nx, g.ny, g.nz, 0);
+    hipLaunchKernelGGL(k_sat_axis, dim3(nblk(g.nx * g.nz, 64)), dim3(64), 0, st, c->d_cell_tot, g.nx, g.ny, g.nz, 1);
+    hipLaunchKernelGGL(k_sat_axis, dim3(nblk(g.nx * g.ny, 64)), dim3(64), 0, st, c->d_cell_tot, g.nx, g.ny, g.nz, 2);
+    hipLaunchKernelGGL(k_deposit_plan, dim3(nblk(c->n_owned, 4)), dim3(256), 0, st, c->hp, c->d_cell_tot, tp, (uint32_t)c->dep_chunk, c->d_items_raw, c->d_n_pieces, c->d_est);
+    hipLaunchKernelGGL(k_items_hist, dim3(nblk(c->n_owned, 256)), dim3(256), 0, st, c->d_items_raw, c->d_n_pieces, c->n_owned, c->d_item_q);
+    hipLaunchKernelGGL(k_items_bases, dim3(1), dim3(64), 0, st, c->d_item_q);
+    hipLaunchKernelGGL(k_items_scatter, dim3(nblk(c->n_owned, 256)), dim3(256), 0, st, c->d_items_raw, c->d_n_pieces, c->n_owned, c->d_item_q, c->d_items);
+    c->est_valid = 1; c->est_range = range;
+    const int blocks = std::max(1, std::min(nblk(c->n_owned, 4) * 4, (int)env_i64("SPPM_DEP_BLOCKS", 256 * 8)));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (c->timing) { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventRecord(e0, st)); }
+    if (c->tap_cap > 0)
+        hipLaunchKernelGGL(k_deposit_tiles<true>, dim3(blocks), dim3(256), 0, st, c->hp, BS.rec_s, BS.cell_start, tp, c->fx_scale, c->d_items, c->d_item_q, c->d_counters, c->d_err);
+    else
+        hipLaunchKernelGGL(k_deposit_tiles<false>, dim3(blocks), dim3(256), 0, st, c->hp, BS.rec_s, BS.cell_start, tp, c->fx_scale, c->d_items, c->d_item_q, c->d_counters, c->d_err);
+    if (c->timing) { HIPCHK(hipEventRecord(e1, st)); c->ev.push_back({e0, e1}); }
+    HIPCHK(hipGetLastError());
+    BS.binned = 0;
+    c->gather_batches++;
+    c->photons_applied += (uint64_t)range;
+    c->rec_first = c->rec_end = 0;
+    HIPCHK(hipMemsetAsync(c->d_rec_count, 0, sizeof(unsigned long long), st));
+    return SPPM_OK;
+}
+
 // grid build + ordered gather over whatever is in the unsorted record buffer; clears the buffer
 extern "C" int sppm_gather(sppm_ctx* c)
 {
@@ -1333,7 +1402,8 @@ extern "C" int sppm_gather(sppm_ctx* c)
                            (long long)c->cfg.gather_max, c->d_err, c->d_qmax);
         HIPCHK(hipGetLastError());
     }
-    return c->gather_mode ? gather_tiles(c) : gather_simple(c);
+    if (!c->gather_mode) return gather_simple(c);
+    return c->cfg.update_rule == 1 ? deposit_tiles(c) : gather_tiles(c);
 }
 
 static int64_t batch_size(const sppm_ctx* c, uint64_t applied)
@@ -1341,7 +1411,7 @@ static int64_t batch_size(const sppm_ctx* c, uint64_t applied)
     // Batches grow with the photons already applied: the radii shrink like N^-0.43, so a batch about
     // half as long as the history changes them little while it runs.
     int64_t n = c->batch_photons;
-    if (c->gather_mode) n = std::min<int64_t>(n, std::max<int64_t>(32768, (int64_t)(applied / 2)));
+    if (c->gather_mode && c->cfg.update_rule == 0) n = std::min<int64_t>(n, std::max<int64_t>(32768, (int64_t)(applied / 2)));
     return n;
 }
 
@@ -1467,7 +1537,7 @@ extern "C" int sppm_end_pass(sppm_ctx* c)
     if (!c) return fail(SPPM_ERR_INVALID, "sppm_end_pass: null context");
     CTX_DEVICE(c, "sppm_end_pass");
     if (c->cfg.update_rule != 1 || c->P == 0) return SPPM_OK;
-    hipLaunchKernelGGL(k_end_pass, dim3(nblk(c->P, 256)), dim3(256), 0, c->stream, c->hp, own_of(c), c->cfg.alpha);
+    hipLaunchKernelGGL(k_end_pass, dim3(nblk(c->P, 256)), dim3(256), 0, c->stream, c->hp, scene_of(c), own_of(c), c->cfg.alpha, 1.0 / c->fx_scale, c->d_err);
     HIPCHK(hipGetLastError());
     return SPPM_OK;
 }
@@ -1581,6 +1651,7 @@ extern "C" int sppm_check(sppm_ctx* c)
     if (err[3]) return fail(SPPM_ERR_STATE, "a record's photon index lies outside the range declared for the batch");
     if (err[4]) return fail(SPPM_ERR_OVERFLOW, "reference-stream mode: a path ran past the uploaded part of the stream");
     if (err[5]) return fail(SPPM_ERR_STATE, "reference-stream mode: a pixel consumed a different number of draws than the offset walk found");
+    if (err[6]) return fail(SPPM_ERR_OVERFLOW, "per-pass rule: a deposit left the fixed-point range (a photon flux above 8192 x the emitted flux, or 2^21 deposits on one hitpoint in one pass)");
     return SPPM_OK;
 }
 
@@ -1696,6 +1767,34 @@ extern "C" int sppm_import_state(sppm_ctx* c, const double* d_in)
     if (c->P == 0) return SPPM_OK;
     hipLaunchKernelGGL(k_import_state, dim3(nblk(c->P, 256)), dim3(256), 0, c->stream, c->hp, d_in);
     HIPCHK(hipGetLastError());
+    return SPPM_OK;
+}
+
+// The per-pass rule between ranks: the pass's deposits, dep[4][P] 64-bit integers (fixed-point flux x, y, z and the
+// count M).  Every rank deposits the photons it traced into its own copy; the sum over the ranks -- integers, so
+// exact and independent of the number of ranks -- is stored back before sppm_end_pass.
+extern "C" int sppm_export_deposits(sppm_ctx* c, int64_t* d_out)
+{
+    if (!c || !d_out) return fail(SPPM_ERR_INVALID, "sppm_export_deposits: null argument");
+    CTX_DEVICE(c, "sppm_export_deposits");
+    if (c->cfg.update_rule != 1) return fail(SPPM_ERR_STATE, "sppm_export_deposits: update_rule 1 only");
+    if (c->P > 0) HIPCHK(hipMemcpyAsync(d_out, c->hp.dep, 4 * (size_t)c->P * sizeof(int64_t), hipMemcpyDeviceToDevice, c->stream));
+    return SPPM_OK;
+}
+
+extern "C" int sppm_import_deposits(sppm_ctx* c, const int64_t* d_in)
+{
+    if (!c || !d_in) return fail(SPPM_ERR_INVALID, "sppm_import_deposits: null argument");
+    CTX_DEVICE(c, "sppm_import_deposits");
+    if (c->cfg.update_rule != 1) return fail(SPPM_ERR_STATE, "sppm_import_deposits: update_rule 1 only");
+    if (c->P > 0) HIPCHK(hipMemcpyAsync(c->hp.dep, d_in, 4 * (size_t)c->P * sizeof(int64_t), hipMemcpyDeviceToDevice, c->stream));
+    return SPPM_OK;
+}
+
+extern "C" int sppm_fixed_point_scale(sppm_ctx* c, double* scale)
+{
+    if (!c || !scale) return fail(SPPM_ERR_INVALID, "sppm_fixed_point_scale: null argument");
+    *scale = c->fx_scale;
     return SPPM_OK;
 }
 

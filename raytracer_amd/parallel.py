@@ -35,21 +35,42 @@ def owner_of_pixels(width, height, world):
 
 
 class ShardedSppm:
-    def __init__(self, width, height, photons_per_rank, rank=0, world=1, exchange="allgather", ownership=1,
-                 spheres=scene.CORNELL_SPHERES, photons_total=None, **cfg_kw):
-        if exchange not in ("replicate", "allgather"):
-            raise ValueError("exchange must be 'replicate' or 'allgather'")
+    """rule 0 (default): the reference's per-photon update, exact for any world size: hitpoints partitioned, photon
+    records exchanged (`exchange`).  rule 1: the per-pass update -- north_star's split: every rank keeps ALL hitpoints,
+    traces photons [rank*M/world, (rank+1)*M/world) of the pass (streams keyed by global photon index) and deposits
+    them into 64-bit fixed-point accumulators; ONE all-reduce (sum) of the accumulators per pass (4 x 8 bytes per
+    hitpoint: 66 MB at 1080p), then every rank applies the same end-of-pass update.  Integer sums are exact, so the
+    result is bit-identical for every world size."""
+
+    def __init__(self, width, height, photons_per_rank, rank=0, world=1, exchange=None, ownership=1,
+                 spheres=scene.CORNELL_SPHERES, photons_total=None, rule=0, **cfg_kw):
+        if rule not in (0, 1):
+            raise ValueError("rule must be 0 (per-photon update, sppm2.h) or 1 (per-pass update, stochastic_ppm.h)")
+        if exchange is None:
+            exchange = "allreduce" if rule == 1 else "allgather"
+        if rule == 1 and exchange != "allreduce":
+            raise ValueError("rule 1 exchanges the per-hitpoint accumulators: exchange='allreduce'")
+        if rule == 0 and exchange not in ("replicate", "allgather"):
+            raise ValueError("rule 0: exchange must be 'replicate' or 'allgather'")
         self.W, self.H, self.P = width, height, width * height
         self.rank, self.world = rank, world
         self.M_rank = photons_per_rank
         self.M = photons_per_rank * world
-        self.exchange = exchange if world > 1 else "replicate"
+        self.rule = rule
+        self.exchange = exchange if (world > 1 or rule == 1) else "replicate"
         self.replicated_trace = self.exchange == "replicate"
         self.ownership = ownership
+        self.exchanged_bytes = 0   # bytes this rank handed to collectives (payload, both directions counted once)
+        self.stage_events = []     # (name, start event, end event) on the current stream, when time_stages is set
+        self.time_stages = False
         # photons_total: the photon streams are keyed over this many photons (classic PPM: every step's photons belong to ONE run)
-        cfg = sppm.make_config(width, height, photons_per_pass=photons_total or self.M, tile_first=rank, tile_stride=world, ownership=ownership, **cfg_kw)
+        if rule == 1:  # all hitpoints on every rank
+            cfg = sppm.make_config(width, height, photons_per_pass=photons_total or self.M, update_rule=1, **cfg_kw)
+        else:
+            cfg = sppm.make_config(width, height, photons_per_pass=photons_total or self.M, tile_first=rank, tile_stride=world, ownership=ownership, **cfg_kw)
         self.ctx = sppm.SppmContext(cfg, spheres)
         self.image = None
+        self._dep = None
         self._rows = self._all = self._side = self._next = None
         self.total_passes = None   # if set, nothing is started ahead for passes >= total_passes
         self.batch_photons = 1 << 20 if world == 1 else (1 << 20) * world  # photons of all ranks per batch
@@ -58,6 +79,8 @@ class ShardedSppm:
     def describe(self):
         if self.world == 1:
             return "1 GPU"
+        if self.rule == 1:
+            return f"{self.world} ranks: photons sharded by global index, hitpoints replicated, one all-reduce of the fixed-point deposits per pass"
         how = "ranges of the hitpoints' Morton order" if self.ownership == 1 else "8x8 hitpoint tiles dealt round-robin"
         return f"{self.world} ranks: hitpoints by {how}, photon records by {self.exchange}"
 
@@ -65,7 +88,10 @@ class ShardedSppm:
         """One SPPM pass: eye pass, photon pass of self.M photons, progressive update, image resolve."""
         ctx = self.ctx
         ctx.eye_pass(i)
-        if self.replicated_trace:
+        if self.rule == 1:
+            ctx.photon_pass(i, self.M_rank, first=self.rank * self.M_rank)
+            self._allreduce_deposits()
+        elif self.replicated_trace:
             ctx.photon_pass(i, self.M)
         else:
             self._photon_pass_allgather(i)
@@ -73,6 +99,25 @@ class ShardedSppm:
         if resolve:
             self.image = ctx.resolve(i, self.M)
         return self.image
+
+    # ---- per-pass rule: one all-reduce of the deposits ---------------------------------------------------
+    def _allreduce_deposits(self):
+        """sum the ranks' accumulators [4][P] (int64) in place and hand the sum back to the context; the next pass's
+        tracing and eye pass already run on the context's look-ahead streams meanwhile"""
+        if self.world == 1:
+            return
+        import torch
+        ev = None
+        if self.time_stages:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        self._dep = self.ctx.export_deposits(self._dep)
+        all_reduce_sum(self._dep)
+        self.ctx.import_deposits(self._dep)
+        self.exchanged_bytes += self._dep.numel() * 8
+        if ev:
+            ev[1].record()
+            self.stage_events.append(("exchange",) + ev)
 
     # ---- all-gather exchange, pipelined --------------------------------------------------------------------
     def _batch_size(self, done):
@@ -146,8 +191,7 @@ class ShardedSppm:
     def gather_image(self):
         """Full image on every rank: a rank's resolve is valid on the hitpoints it owns; the others are zeroed and
         one all-reduce sums the ranks (exactly one non-zero term per pixel)."""
-        import torch.distributed as dist
-        if self.world == 1:
+        if self.world == 1 or self.rule == 1:   # rule 1: every rank holds all hitpoints
             return self.image
         out = self.image * self.ctx.owned_mask().to(self.image.dtype).unsqueeze(1)
         all_reduce_sum(out)

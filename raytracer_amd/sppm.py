@@ -168,6 +168,23 @@ class SppmContext:
         capi.check(self.L.sppm_import_state(self.h, state.data_ptr()))
         self._keep = state  # the copy is asynchronous
 
+    def export_deposits(self, out=None):
+        """update_rule 1: int64 tensor [4][hitpoints] = this rank's deposits of the pass so far (fixed-point flux, M)."""
+        if out is None:
+            out = self.torch.empty((4, self.n_hitpoints), dtype=self.torch.int64, device=self.device)
+        capi.check(self.L.sppm_export_deposits(self.h, out.data_ptr()))
+        return out
+
+    def import_deposits(self, dep):
+        assert dep.dtype == self.torch.int64 and tuple(dep.shape) == (4, self.n_hitpoints) and dep.is_contiguous() and dep.device == self.device
+        capi.check(self.L.sppm_import_deposits(self.h, dep.data_ptr()))
+        self._keep_dep = dep  # the copy is asynchronous
+
+    def fixed_point_scale(self):
+        v = C.c_double()
+        capi.check(self.L.sppm_fixed_point_scale(self.h, C.byref(v)))
+        return v.value
+
     # ---- taps ------------------------------------------------------------------------------------
     def hitpoint_pixels(self):
         """classic PPM: image index of every hitpoint of the list, in creation order."""

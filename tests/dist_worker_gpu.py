@@ -48,6 +48,17 @@ def main():
         job.close()
         dist.destroy_process_group()
         return
+    if exchange == "allreduce":  # north_star's split: per-pass rule, photons sharded, hitpoints replicated, one all-reduce per pass
+        job = ShardedSppm(W, H, photons_per_rank=M_rank, rank=rank, world=world, rule=1)
+        for i in range(passes):
+            job.step(i)
+        job.ctx.check()
+        hp = job.ctx.hitpoints()
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), image=job.gather_image().cpu().numpy(), n=hp["n"], r2=hp["r2"], flux=hp["flux"],
+                 exchanged=job.exchanged_bytes)
+        job.close()
+        dist.destroy_process_group()
+        return
     job = ShardedSppm(W, H, photons_per_rank=M_rank, rank=rank, world=world, exchange=exchange, ownership=ownership)
     job.total_passes = passes
     for i in range(passes):

@@ -56,6 +56,10 @@ def lib():
     L.orc_resolve.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p]
     L.orc_get_state.argtypes = [C.c_void_p] + [C.c_void_p] * 7
     L.orc_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.orc_get_deposits.restype = C.c_int
+    L.orc_get_deposits.argtypes = [C.c_void_p, C.c_void_p]
+    L.orc_fixed_scale.restype = C.c_double
+    L.orc_fixed_scale.argtypes = [C.c_void_p]
     L.orc_mt_samples.argtypes = [C.c_uint32, C.c_int, C.c_void_p]
     L.orc_xorshift.argtypes = [C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]
     L.orc_xs_stream.argtypes = [C.c_uint32, C.c_uint64, C.c_int, C.c_void_p]
@@ -176,6 +180,15 @@ class Oracle:
         self.L.orc_get_state(self.h, _p(s["valid"]), _p(s["obj"]), _p(s["hp_f"]), _p(s["r2"]), _p(s["n"]),
                              _p(s["flux"]), _p(s["ld"]))
         return s
+
+    def deposits(self):
+        """rule 1: (dep[P][4] int64 = fixed-point flux sums and M of the pass so far, the clamp flag)"""
+        d = np.zeros((self.P, 4), np.int64)
+        flag = self.L.orc_get_deposits(self.h, _p(d))
+        return d, flag
+
+    def fixed_scale(self):
+        return self.L.orc_fixed_scale(self.h)
 
     def counters(self):
         a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()

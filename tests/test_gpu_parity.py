@@ -172,22 +172,6 @@ def test_config1_320x240_matches_oracle():
     ctx.close()
 
 
-def test_per_pass_rule_matches_oracle():
-    """update_rule 1 (src/stochastic_ppm.h:721-741)."""
-    W, H, M = 64, 48, 20000
-    ctx, orc = _pair(W, H, M, update_rule=1)
-    for i in range(3):
-        ctx.eye_pass(i); orc.eye_pass(i)
-        ctx.photon_pass(i, M); orc.photon_pass(i, M)
-        ctx.end_pass(); orc.end_pass()
-        s, o = ctx.hitpoints(), orc.state()
-        for k in ("n", "r2", "flux", "ld"):
-            _same(s[k], o[k], f"pass {i} {k}")
-        _same(ctx.resolve(i, M).cpu().numpy(), orc.resolve(i, M), f"pass {i} image")
-    ctx.check()
-    ctx.close()
-
-
 def test_record_exchange_equals_local_tracing():
     """The all-gather path of a 2-rank run, emulated with two contexts on one GPU: each 'rank' traces
     half of the photons, the packed records are exchanged through sppm_pack_records /

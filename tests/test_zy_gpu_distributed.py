@@ -58,6 +58,32 @@ def test_two_ranks_equal_one_gpu(tmp_path, exchange, ownership):
         assert (a.view(np.uint64) == b.view(np.uint64)).all() if a.dtype.kind == "f" else (a == b).all(), k
 
 
+def test_two_ranks_per_pass_rule_equal_one_gpu(tmp_path):
+    """north_star's multi-GPU path (ShardedSppm(rule=1)): each rank traces half of every pass's photons and deposits them
+    into its copy of all hitpoints, one all-reduce of the 64-bit fixed-point deposits per pass, the same end-of-pass
+    update on every rank.  State and image on BOTH ranks equal a single-GPU run of the per-pass rule bit for bit."""
+    world, W, H, M_rank, passes = 2, 96, 64, 24000, 3
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = 29900 + os.getpid() % 1000
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker_gpu.py"), str(tmp_path), "allreduce", "0"]
+    res = _run(cmd, env)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    M = M_rank * world
+    ctx = sppm.SppmContext(sppm.make_config(W, H, photons_per_pass=M, update_rule=1))
+    for i in range(passes):
+        ctx.eye_pass(i); ctx.photon_pass(i, M); ctx.end_pass()
+    ref_img, ref = ctx.resolve(passes - 1, M).cpu().numpy(), ctx.hitpoints()
+    ctx.check(); ctx.close()
+    for r in range(world):
+        g = np.load(tmp_path / f"rank{r}.npz")
+        assert (g["image"].view(np.uint64) == ref_img.view(np.uint64)).all(), "image on a rank differs from the single-GPU image"
+        for k in ("n", "r2", "flux"):
+            a, b = np.ascontiguousarray(g[k]), np.ascontiguousarray(ref[k])
+            assert (a.view(np.uint64) == b.view(np.uint64)).all() if a.dtype.kind == "f" else (a == b).all(), k
+        assert int(g["exchanged"]) == passes * 4 * 8 * W * H   # 32 bytes per hitpoint and pass
+
+
 def test_two_ranks_classic_ppm_equal_one_gpu(tmp_path):
     """ShardedPpm: the hitpoint list shared out by ranges of its Morton order, photon records by all-gather, the owned
     state summed over the ranks at the end: state and image on every rank equal a single-GPU render, bit for bit."""
