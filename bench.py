@@ -236,6 +236,9 @@ def main():
     ap.add_argument("--workload", choices=("sppm", "ppm"), default="sppm", help="sppm: BASELINE config 2/3 (the metric's workload); ppm: config 4, classic PPM")
     ap.add_argument("--spheres", type=int, default=0, help="sppm workload: N > 0 replaces the Cornell scene by raytracer_amd.scene.synthetic_spheres(N) "
                     "(BASELINE config 5: --spheres 10000 --width 3840 --height 2160); rays then walk a grid over the spheres")
+    ap.add_argument("--rule", type=int, choices=(0, 1), default=0, help="sppm workload: 0 = the reference's per-photon update (src/sppm2.h:391-421; N > 1: hitpoints "
+                    "partitioned, photon records exchanged); 1 = the per-pass update (src/stochastic_ppm.h:721-741; N > 1: photons sharded, hitpoints "
+                    "replicated, one all-reduce of the fixed-point deposits per pass -- north_star's split)")
     ap.add_argument("--supersamples", type=int, default=1, help="--workload ppm only")
     ap.add_argument("--radius2", type=float, default=5.0, help="--workload ppm only: InitialRadius = gather radius (squared), src/main.cpp:76-77")
     args = ap.parse_args()
@@ -280,13 +283,13 @@ def main():
     scene_name = f"{args.spheres}-sphere synthetic scene (scene.synthetic_spheres, seed 20260517) in the Cornell box" if args.spheres > 0 else "Cornell-box"
 
     if args.warmup > 0:  # untimed: a scratch render of W passes
-        scratch = ShardedSppm(W, H, photons_per_rank=M, rank=rank, world=world, spheres=table)
+        scratch = ShardedSppm(W, H, photons_per_rank=M, rank=rank, world=world, spheres=table, rule=args.rule)
         scratch.total_passes = args.warmup
         for i in range(args.warmup):
             scratch.step(i)
         scratch.ctx.check()
         scratch.close()
-    job = ShardedSppm(W, H, photons_per_rank=M, rank=rank, world=world, spheres=table)
+    job = ShardedSppm(W, H, photons_per_rank=M, rank=rank, world=world, spheres=table, rule=args.rule)
     job.total_passes = args.steps
     job.ctx.set_timing(True)
     c0 = job.ctx.counters()
@@ -331,12 +334,12 @@ def main():
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{scene_name} SPPM {W}x{H}, {M} photons/pass/GPU, passes 0..{args.steps - 1} "
-                                   f"of a fresh render, alpha 0.7, initial r^2 25, search r^2 25, per-photon update (sppm2.h), "
+                                   f"of a fresh render, alpha 0.7, initial r^2 25, search r^2 25, {'per-photon update (sppm2.h)' if args.rule == 0 else 'per-pass update (stochastic_ppm.h:721-741), deposits in 64-bit fixed point'}, "
                                    f"XorShift streams", "photons_per_pass": M * world, "width": W, "height": H,
                        "parallelism": job.describe()},
             "hitpoint_updates_per_s": upd / dt, "rays_per_s": rays / dt, "records_per_photon": records / max(1.0, float(M) * args.steps * (world if job.replicated_trace else 1)),
             "updates_per_photon": upd / photons_total,
-            "roofline": {"bound": "hbm", "kernel": "k_gather_tiles", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "k_gather_tiles" if args.rule == 0 else "k_deposit_tiles", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": None,
                          "launches": int(g_launch), "avg_launch_ms": g_ns / 1e6 / g_launch,
                          "alg_bytes_per_launch": alg_bytes / g_launch,

@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsppm_hip.so")
+LIB_PATH = os.environ.get("SPPM_HIP_LIB") or os.path.join(_HERE, "libsppm_hip.so")  # SPPM_HIP_LIB: another build of the same library (tuning experiments)
 
 SYMBOLS = [
     "sppm_last_error", "sppm_device_count", "sppm_create", "sppm_destroy", "sppm_camera_rays", "sppm_intersect",

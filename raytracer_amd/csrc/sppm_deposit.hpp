@@ -18,6 +18,15 @@
 
 // (fx_fix, the fixed point of the deposits, is defined in sppm_gather_simple.hpp, which also uses it)
 
+// A wavefront holds DEP_H hitpoints per lane: a tile of the deposit is 64 * DEP_H consecutive hitpoints of the
+// Morton order (lane l holds entries l, 64 + l, ...).  Every staged record is read from LDS once per wavefront
+// (a broadcast of 72 bytes, which costs the same LDS cycles whether one lane or 64 want it), so with one hitpoint
+// per lane the kernel was bound by the LDS pipe that the four SIMDs of a CU share; two hitpoints per lane halve
+// the LDS reads per (record, hitpoint) pair and leave it bound by the tests' arithmetic.
+#ifndef DEP_H
+#define DEP_H 1  // 2 was measured: 18 % more pair tests per second, but tiles of 128 hitpoints test a third more pairs per update
+#endif
+#define DEP_TILE (64 * DEP_H)
 // work item: tile << 12 | cluster << 8 | chunk << 4 | (chunks - 1)
 #define DEP_MAX_CLUSTERS 16
 #define DEP_MAX_CHUNKS 16
@@ -25,55 +34,116 @@ __device__ __forceinline__ uint32_t pack_dep_item(int tile, int cluster, int chu
 {
     return ((uint32_t)tile << 12) | ((uint32_t)cluster << 8) | ((uint32_t)chunk << 4) | (uint32_t)(chunks - 1);
 }
+// ballot without the bool -> int -> compare round trip of __ballot
+__device__ __forceinline__ unsigned long long ballot64(bool b) { return __builtin_amdgcn_ballot_w64(b); }
 
-// The lanes of cluster `c` of a tile, same rule in the plan and in the deposit: the first remaining lane is the
-// seed, lanes within cluster_d (max norm) of it join; the last cluster takes whatever is left.
-__device__ __forceinline__ bool dep_next_cluster(unsigned long long& remaining, int c, bool live, int lane, double x, double y, double z, double cluster_d)
+// The hitpoints of a deposit tile, DEP_H per lane, and what the plan and the deposit both derive from them.
+struct DepTile {
+    int p[DEP_H]; bool live[DEP_H];
+    double x[DEP_H], y[DEP_H], z[DEP_H], r2[DEP_H];
+};
+__device__ __forceinline__ bool dep_load_tile(const HpArrays& hp, const TileParams& tp, int k, int lane, DepTile& t)
 {
-    const int seed = __ffsll((long long)remaining) - 1;
-    const double sx = rl_d(x, seed), sy = rl_d(y, seed), sz = rl_d(z, seed);
-    const bool inc = live && ((remaining >> lane) & 1ull) &&
-                     (c == DEP_MAX_CLUSTERS - 1 || (fabs(x - sx) <= cluster_d && fabs(y - sy) <= cluster_d && fabs(z - sz) <= cluster_d));
-    remaining &= ~__ballot(inc);
-    return inc;
+    const int P = hp.P;
+    bool any = false;
+#pragma unroll
+    for (int h = 0; h < DEP_H; h++) {
+        const int slot = k * DEP_TILE + h * 64 + lane;
+        t.p[h] = slot < tp.n_pix ? tp.order[slot] : 0;
+        t.live[h] = slot < tp.n_pix;
+        if (t.live[h]) t.live[h] = hp.valid[t.p[h]] != 0;
+        t.x[h] = t.live[h] ? hp.pos[t.p[h]] : 0.0; t.y[h] = t.live[h] ? hp.pos[P + t.p[h]] : 0.0; t.z[h] = t.live[h] ? hp.pos[2 * P + t.p[h]] : 0.0;
+        t.r2[h] = t.live[h] ? hp.r2[t.p[h]] : 0.0;
+        any = any || t.live[h];
+    }
+    return ballot64(any) != 0ull;
+}
+// The hitpoints of cluster `c` of a tile, same rule in the plan and in the deposit: the first remaining hitpoint
+// (lowest h, then lowest lane) is the seed, hitpoints within cluster_d (max norm) of it join; the last cluster
+// takes whatever is left.  remaining[h] = ballot of the hitpoints not yet in a cluster.
+__device__ __forceinline__ void dep_next_cluster(unsigned long long (&remaining)[DEP_H], int c, const DepTile& t, int lane, double cluster_d, bool (&inc)[DEP_H])
+{
+    int sh = 0;
+#pragma unroll
+    for (int h = DEP_H - 1; h >= 0; h--) if (remaining[h]) sh = h;
+    unsigned long long rs = remaining[0];
+    double xs = t.x[0], ys = t.y[0], zs = t.z[0];
+#pragma unroll
+    for (int h = 1; h < DEP_H; h++) if (sh == h) { rs = remaining[h]; xs = t.x[h]; ys = t.y[h]; zs = t.z[h]; }
+    const int seed = __ffsll((long long)rs) - 1;
+    const double sx = rl_d(xs, seed), sy = rl_d(ys, seed), sz = rl_d(zs, seed);
+#pragma unroll
+    for (int h = 0; h < DEP_H; h++) {
+        inc[h] = t.live[h] && ((remaining[h] >> lane) & 1ull) &&
+                 (c == DEP_MAX_CLUSTERS - 1 || (fabs(t.x[h] - sx) <= cluster_d && fabs(t.y[h] - sy) <= cluster_d && fabs(t.z[h] - sz) <= cluster_d));
+        remaining[h] &= ~ballot64(inc[h]);
+    }
+}
+__device__ __forceinline__ bool dep_any(const unsigned long long (&m)[DEP_H])
+{
+    unsigned long long a = 0;
+#pragma unroll
+    for (int h = 0; h < DEP_H; h++) a |= m[h];
+    return a != 0ull;
+}
+// region of a cluster: its bounding box and its largest radius (grown a little: the cell range must cover every
+// record a hitpoint of the cluster can accept)
+struct DepRegion { double bx0, bx1, by0, by1, bz0, bz1, rmax; int cx0, cx1, cy0, cy1, cz0, cz1; unsigned int n_inc; };
+__device__ __forceinline__ DepRegion dep_region(const DepTile& t, const bool (&inc)[DEP_H], const TileParams& tp)
+{
+    const double BIG = 1e300;
+    double lx = BIG, hx = -BIG, ly = BIG, hy = -BIG, lz = BIG, hz = -BIG, rr = 0.0;
+    unsigned int n = 0;
+#pragma unroll
+    for (int h = 0; h < DEP_H; h++) {
+        if (inc[h]) {
+            lx = fmin(lx, t.x[h]); hx = fmax(hx, t.x[h]); ly = fmin(ly, t.y[h]); hy = fmax(hy, t.y[h]); lz = fmin(lz, t.z[h]); hz = fmax(hz, t.z[h]);
+            rr = fmax(rr, sqrt(fmin(t.r2[h], tp.gather_r2)) * (1.0 + 1e-9) + 1e-9);
+        }
+        n += (unsigned int)__popcll(ballot64(inc[h]));
+    }
+    DepRegion R;
+    R.n_inc = n;
+    R.rmax = wave_max_d(rr);
+    R.bx0 = wave_min_d(lx); R.bx1 = wave_max_d(hx); R.by0 = wave_min_d(ly); R.by1 = wave_max_d(hy); R.bz0 = wave_min_d(lz); R.bz1 = wave_max_d(hz);
+    R.cx0 = __builtin_amdgcn_readfirstlane(grid_coord(R.bx0 - R.rmax, tp.g.ox, tp.g.inv_c, tp.g.nx));
+    R.cx1 = __builtin_amdgcn_readfirstlane(grid_coord(R.bx1 + R.rmax, tp.g.ox, tp.g.inv_c, tp.g.nx));
+    R.cy0 = __builtin_amdgcn_readfirstlane(grid_coord(R.by0 - R.rmax, tp.g.oy, tp.g.inv_c, tp.g.ny));
+    R.cy1 = __builtin_amdgcn_readfirstlane(grid_coord(R.by1 + R.rmax, tp.g.oy, tp.g.inv_c, tp.g.ny));
+    R.cz0 = __builtin_amdgcn_readfirstlane(grid_coord(R.bz0 - R.rmax, tp.g.oz, tp.g.inv_c, tp.g.nz));
+    R.cz1 = __builtin_amdgcn_readfirstlane(grid_coord(R.bz1 + R.rmax, tp.g.oz, tp.g.inv_c, tp.g.nz));
+    return R;
 }
 
 // One wavefront per tile: the clusters, the records in each cluster's region (8 lookups in the summed-area
 // table), and the cut of every region's records into at most DEP_MAX_CHUNKS chunks of ~chunk_records.  Tile k
 // writes its pieces to raw[k*64 ..] as (cost estimate << 32 | item) and their number (<= 64) to n_pieces[k].
-__global__ void __launch_bounds__(256) k_deposit_plan(HpArrays hp, const uint32_t* __restrict__ sat, TileParams tp, uint32_t chunk_records,
+__global__ void __launch_bounds__(256) k_deposit_plan(HpArrays hp, const uint32_t* __restrict__ sat, TileParams tp, int n_tiles, uint32_t chunk_records,
                                                       unsigned long long* __restrict__ raw, uint8_t* __restrict__ n_pieces, uint32_t* __restrict__ est)
 {
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int k = blockIdx.x * 4 + wv;
-    if (k >= tp.n_owned) return;
-    const int slot = k * 64 + lane;
-    const int P = hp.P;
-    const int p = slot < tp.n_pix ? tp.order[slot] : 0;
-    bool live = slot < tp.n_pix;
-    if (live) live = hp.valid[p] != 0;
-    if (__ballot(live) == 0) { if (lane == 0) { est[k] = 0; n_pieces[k] = 0; } return; }
-    const double BIG = 1e300;
-    const double x = live ? hp.pos[p] : 0.0, y = live ? hp.pos[P + p] : 0.0, z = live ? hp.pos[2 * P + p] : 0.0;
-    const double rr = live ? sqrt(fmin(hp.r2[p], tp.gather_r2)) * (1.0 + 1e-9) + 1e-9 : 0.0;
-    unsigned long long remaining = __ballot(live);
+    if (k >= n_tiles) return;
+    DepTile t;
+    if (!dep_load_tile(hp, tp, k, lane, t)) { if (lane == 0) { est[k] = 0; n_pieces[k] = 0; } return; }
+    unsigned long long remaining[DEP_H];
+#pragma unroll
+    for (int h = 0; h < DEP_H; h++) remaining[h] = ballot64(t.live[h]);
     int n_out = 0;
     unsigned int total = 0;
-    for (int c = 0; remaining; c++) {
-        const bool inc = dep_next_cluster(remaining, c, live, lane, x, y, z, tp.cluster_d);
-        const double rm = wave_max_d(inc ? rr : 0.0);
-        const int cx0 = grid_coord(wave_min_d(inc ? x : BIG) - rm, tp.g.ox, tp.g.inv_c, tp.g.nx), cx1 = grid_coord(wave_max_d(inc ? x : -BIG) + rm, tp.g.ox, tp.g.inv_c, tp.g.nx);
-        const int cy0 = grid_coord(wave_min_d(inc ? y : BIG) - rm, tp.g.oy, tp.g.inv_c, tp.g.ny), cy1 = grid_coord(wave_max_d(inc ? y : -BIG) + rm, tp.g.oy, tp.g.inv_c, tp.g.ny);
-        const int cz0 = grid_coord(wave_min_d(inc ? z : BIG) - rm, tp.g.oz, tp.g.inv_c, tp.g.nz), cz1 = grid_coord(wave_max_d(inc ? z : -BIG) + rm, tp.g.oz, tp.g.inv_c, tp.g.nz);
-        const unsigned int T = sat_box(sat, tp.g.nx, tp.g.ny, cx0, cx1, cy0, cy1, cz0, cz1, lane);
-        const unsigned int cells = (unsigned int)((cx1 - cx0 + 1) * (cy1 - cy0 + 1) * (cz1 - cz0 + 1));
+    for (int c = 0; dep_any(remaining); c++) {
+        bool inc[DEP_H];
+        dep_next_cluster(remaining, c, t, lane, tp.cluster_d, inc);
+        const DepRegion R = dep_region(t, inc, tp);
+        const unsigned int T = sat_box(sat, tp.g.nx, tp.g.ny, R.cx0, R.cx1, R.cy0, R.cy1, R.cz0, R.cz1, lane);
+        const unsigned int cells = (unsigned int)((R.cx1 - R.cx0 + 1) * (R.cy1 - R.cy0 + 1) * (R.cz1 - R.cz0 + 1));
         // every later cluster (at most DEP_MAX_CLUSTERS - 1 - c of them) keeps one of the tile's 64 slots
         const int avail = 64 - n_out - (DEP_MAX_CLUSTERS - 1 - c);
         int cn = (int)((T + chunk_records - 1) / chunk_records);
         cn = cn < 1 ? 1 : cn;
         cn = cn > DEP_MAX_CHUNKS ? DEP_MAX_CHUNKS : cn;
         cn = cn > avail ? avail : cn;
-        // a piece stages its share of the records and walks all the region's cells (twice)
+        // a piece stages its share of the records and walks the region's cells
         const unsigned int cost = T / (unsigned int)cn + 16u + (cells >> 3);
         if (lane < cn) raw[(size_t)k * 64 + n_out + lane] = ((unsigned long long)cost << 32) | pack_dep_item(k, c, lane, cn);
         n_out += cn;
@@ -82,22 +152,31 @@ __global__ void __launch_bounds__(256) k_deposit_plan(HpArrays hp, const uint32_
     if (lane == 0) { est[k] = total; n_pieces[k] = (uint8_t)n_out; }
 }
 
-template <bool TAP>
-__global__ void __launch_bounds__(256) k_deposit_tiles(HpArrays hp, RecArrays rec, const uint32_t* __restrict__ cell_start, TileParams tp, double fx_scale,
+#ifndef DEP_WAVES
+#define DEP_WAVES (DEP_H == 1 ? 4 : 3)  // register budget: 512 / DEP_WAVES per lane
+#endif
+#define DEP_ATTR __attribute__((amdgpu_waves_per_eu(DEP_WAVES, DEP_WAVES)))
+#define DEP_ROWS 64  // staged records per wavefront: one group of candidates at a time, processed while the next group's loads are in flight
+template <bool TAP, bool STAMPS = false>
+__global__ void __launch_bounds__(256) DEP_ATTR k_deposit_tiles(HpArrays hp, RecArrays rec, const uint32_t* __restrict__ cell_start, TileParams tp, double fx_scale,
                                                        const uint32_t* __restrict__ items, unsigned int* __restrict__ q,
                                                        unsigned long long* __restrict__ counters, int32_t* __restrict__ err)
 {
-    __shared__ double s_row[4][64][10];  // a staged record: position, geometric normal, fixed-point flux (3 x int64 bits), key bits
+    constexpr int ROW = TAP ? 10 : 9;
+    __shared__ double s_row[4][DEP_ROWS][ROW];  // a staged record: position, geometric normal, fixed-point flux (3 x int64 bits)[, key bits]
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int P = hp.P;
-    const double BIG = 1e300;
     const double thr = tp.gather_r2 * 0.01;
     const double band_rel = 1e-9 + 8e-15 / thr;
+    const double thr2_lo = thr * thr * (1.0 - band_rel), thr2_hi = thr * thr * (1.0 + band_rel);
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const int64_t cap = rec.cap;
     const unsigned int n_items = q[0];
     const unsigned int n_waves = gridDim.x * 4u;
+#define DSTAMP() (STAMPS ? (unsigned long long)__builtin_amdgcn_s_memtime() : 0ull)
+    unsigned long long st_setup = 0, st_count = 0, st_issue = 0, st_append = 0, st_process = 0, st_flush = 0;  // diagnostic build only
     for (bool first_item = true;; first_item = false) {
+    const unsigned long long ts_item = DSTAMP();
     // persistent wavefronts over the list of items, heaviest first (as k_gather_tiles)
     unsigned int item_i = blockIdx.x * 4u + (unsigned int)wv;
     if (!first_item) {
@@ -107,165 +186,225 @@ __global__ void __launch_bounds__(256) k_deposit_tiles(HpArrays hp, RecArrays re
     if (item_i >= n_items) break;
     const uint32_t item = items[item_i];
     const int k = (int)(item >> 12), ci = (int)((item >> 8) & 15u), cj = (int)((item >> 4) & 15u), cn = (int)(item & 15u) + 1;
-    const int slot = k * 64 + lane;
-    const int p = slot < tp.n_pix ? tp.order[slot] : 0;
-    bool live = slot < tp.n_pix;
-    if (live) live = hp.valid[p] != 0;
-    if (__ballot(live) == 0) continue;
-    d3 hpos = mk(0, 0, 0), hn = mk(0, 0, 0);
-    double r2 = 0.0;
-    if (live) {
-        hpos = mk(hp.pos[p], hp.pos[P + p], hp.pos[2 * P + p]);
-        hn = mk(hp.nrm[p], hp.nrm[P + p], hp.nrm[2 * P + p]);
-        r2 = hp.r2[p];
+    DepTile t;
+    if (!dep_load_tile(hp, tp, k, lane, t)) continue;
+    // the hitpoints of cluster ci
+    unsigned long long remaining[DEP_H];
+#pragma unroll
+    for (int h = 0; h < DEP_H; h++) remaining[h] = ballot64(t.live[h]);
+    bool inc[DEP_H];
+#pragma unroll
+    for (int h = 0; h < DEP_H; h++) inc[h] = false;
+    for (int c = 0; c <= ci && dep_any(remaining); c++) {
+        bool in_c[DEP_H];
+        dep_next_cluster(remaining, c, t, lane, tp.cluster_d, in_c);
+#pragma unroll
+        for (int h = 0; h < DEP_H; h++) inc[h] = c == ci && in_c[h];
     }
-    // the lanes of cluster ci
-    unsigned long long remaining = __ballot(live);
-    bool inc = false;
-    for (int c = 0; c <= ci && remaining; c++) {
-        const bool in_c = dep_next_cluster(remaining, c, live, lane, hpos.x, hpos.y, hpos.z, tp.cluster_d);
-        inc = c == ci && in_c;
-    }
-    const unsigned int n_inc = (unsigned int)__popcll(__ballot(inc));
-    if (n_inc == 0) continue;
-    // region: the cluster's bounding box grown by its largest radius
-    const double rr = inc ? sqrt(fmin(r2, tp.gather_r2)) * (1.0 + 1e-9) + 1e-9 : 0.0;
-    const double rmax = wave_max_d(rr);
-    const double rmax2 = rmax * rmax;
-    const double bx0 = wave_min_d(inc ? hpos.x : BIG), bx1 = wave_max_d(inc ? hpos.x : -BIG);
-    const double by0 = wave_min_d(inc ? hpos.y : BIG), by1 = wave_max_d(inc ? hpos.y : -BIG);
-    const double bz0 = wave_min_d(inc ? hpos.z : BIG), bz1 = wave_max_d(inc ? hpos.z : -BIG);
-    const int cx0 = __builtin_amdgcn_readfirstlane(grid_coord(bx0 - rmax, tp.g.ox, tp.g.inv_c, tp.g.nx));
-    const int cx1 = __builtin_amdgcn_readfirstlane(grid_coord(bx1 + rmax, tp.g.ox, tp.g.inv_c, tp.g.nx));
-    const int cy0 = __builtin_amdgcn_readfirstlane(grid_coord(by0 - rmax, tp.g.oy, tp.g.inv_c, tp.g.ny));
-    const int cy1 = __builtin_amdgcn_readfirstlane(grid_coord(by1 + rmax, tp.g.oy, tp.g.inv_c, tp.g.ny));
-    const int cz0 = __builtin_amdgcn_readfirstlane(grid_coord(bz0 - rmax, tp.g.oz, tp.g.inv_c, tp.g.nz));
-    const int cz1 = __builtin_amdgcn_readfirstlane(grid_coord(bz1 + rmax, tp.g.oz, tp.g.inv_c, tp.g.nz));
-    const int kx = cx1 - cx0 + 1, ky = cy1 - cy0 + 1, kz = cz1 - cz0 + 1;
+    const DepRegion R = dep_region(t, inc, tp);
+    if (R.n_inc == 0) continue;
+    const double rmax2 = R.rmax * R.rmax;
+    const int kx = R.cx1 - R.cx0 + 1, ky = R.cy1 - R.cy0 + 1, kz = R.cz1 - R.cz0 + 1;
     const int Ktot = kx * ky * kz;
-    // the region's records form one virtual list (cells in q order): its length, then this item's share of it
-    unsigned int T = 0;
-    for (int qbase = 0; qbase < Ktot; qbase += 64) {
-        const int qi = qbase + lane;
-        uint32_t cnt = 0;
-        if (qi < Ktot) {
-            const int ix = cx0 + qi % kx, iy = cy0 + (qi / kx) % ky, iz = cz0 + qi / (kx * ky);
-            const uint32_t b = (uint32_t)((iz * tp.g.ny + iy) * tp.g.nx + ix);
-            cnt = cell_start[b + 1] - cell_start[b];
+    d3 hn[DEP_H];
+#pragma unroll
+    for (int h = 0; h < DEP_H; h++) hn[h] = inc[h] ? mk(hp.nrm[t.p[h]], hp.nrm[P + t.p[h]], hp.nrm[2 * P + t.p[h]]) : mk(0, 0, 0);
+    // the region's records form one virtual list (cells in q order); an item of a region cut into cn chunks takes
+    // entries [T cj / cn, T (cj + 1) / cn) of it, T = the list's length
+    unsigned int v_lo = 0u, v_hi = 0xFFFFFFFFu;
+    const unsigned long long ts_setup = DSTAMP();
+    st_setup += ts_setup - ts_item;
+    if (cn > 1) {
+        unsigned int T = 0;
+        for (int qbase = 0; qbase < Ktot; qbase += 64) {
+            const int qi = qbase + lane;
+            uint32_t cnt = 0;
+            if (qi < Ktot) {
+                const int ix = R.cx0 + qi % kx, iy = R.cy0 + (qi / kx) % ky, iz = R.cz0 + qi / (kx * ky);
+                const uint32_t b = (uint32_t)((iz * tp.g.ny + iy) * tp.g.nx + ix);
+                cnt = cell_start[b + 1] - cell_start[b];
+            }
+            for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
+            T += (unsigned int)__builtin_amdgcn_readfirstlane((int)cnt);
         }
-        for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
-        T += (unsigned int)__builtin_amdgcn_readfirstlane((int)cnt);
+        v_lo = (unsigned int)((unsigned long long)T * (unsigned int)cj / (unsigned int)cn);
+        v_hi = (unsigned int)((unsigned long long)T * (unsigned int)(cj + 1) / (unsigned int)cn);
     }
-    const unsigned int v_lo = (unsigned int)((unsigned long long)T * (unsigned int)cj / (unsigned int)cn);
-    const unsigned int v_hi = (unsigned int)((unsigned long long)T * (unsigned int)(cj + 1) / (unsigned int)cn);
-    long long ax = 0, ay = 0, az = 0;
-    int am = 0;
+    // Per-hitpoint bounds of the fast test.  The fast path evaluates the squared distance and the two dot products with
+    // fused multiply-adds (three instructions each instead of five); its value differs from the reference's unfused
+    // expression by a few units in the last place of the largest term, so a comparison is only trusted when the
+    // value is farther than 1e-13 (relative; the dot products: absolute) from its bound, and a record for which any
+    // hitpoint is closer than that is evaluated again with the reference's exact operation order (once in ~10^10 pairs).
+    double lim_lo[DEP_H], lim_hi[DEP_H];
+    long long ax[DEP_H], ay[DEP_H], az[DEP_H];
+    int am[DEP_H];
+#pragma unroll
+    for (int h = 0; h < DEP_H; h++) {
+        const double lim = fmin(t.r2[h], tp.gather_r2);  // a record is accepted at d2 < gather_r2 && d2 <= r2
+        lim_lo[h] = inc[h] ? lim * (1.0 - 1e-13) : -1.0; lim_hi[h] = inc[h] ? lim * (1.0 + 1e-13) : -1.0;  // -1: never inside, never too close to call
+        ax[h] = ay[h] = az[h] = 0; am[h] = 0;
+    }
+    st_count += DSTAMP() - ts_setup;
     unsigned int c_sel = 0, c_round = 0;
     unsigned long long c_pairs = 0;
     bool clamped = false;
     int sel_n = 0;
-    // every lane against the sel_n staged records: the search filter of src/kdtree.h:123-127 (its |cos| does not
-    // depend on the orientation of the normal) and the acceptance test of src/stochastic_ppm.h:441-445
-#define DEP_PROCESS()                                                                                                  \
+    // iterator over the list in groups of 64 entries
+    int qbase = -64;
+    unsigned int voff = 0, cbase = 0, i_end = 0;
+    uint32_t g_cs = 0, g_pre = 0;
+    bool pend = false, p_has = false;          // a group whose loads are in flight
+    uint32_t p_r = 0;
+    double p0 = 0, p1 = 0, p2 = 0, p3 = 0, p4 = 0, p5 = 0, p6 = 0, p7 = 0, p8 = 0;
+    unsigned long long p_key = 0;
+#define DEP_ISSUE()                                                                                                    \
     {                                                                                                                  \
-        __builtin_amdgcn_wave_barrier();                                                                               \
-        c_sel += (unsigned int)sel_n; c_pairs += (unsigned long long)sel_n * n_inc; c_round++;                         \
-        const int sel_u = __builtin_amdgcn_readfirstlane(sel_n);                                                        \
-        for (int t = 0; t < sel_u; t++) {                                                                              \
-            const double* row = s_row[wv][t];                                                                          \
-            const d3 g0 = mk(row[3], row[4], row[5]);                                                                  \
-            const d3 dir = hpos - mk(row[0], row[1], row[2]);                                                          \
-            const double d2 = len2(dir);                                                                               \
-            bool ok = inc && (d2 < tp.gather_r2) && (d2 <= r2) && (dot(hn, g0) > 1e-3);                                \
-            if (__ballot(ok) == 0) continue;                                                                           \
-            {                                                                                                          \
-                const double s1 = dot(g0, dir);                                                                        \
-                const double lhs = s1 * s1, rhs = thr * thr * d2;                                                      \
-                const double band = rhs * band_rel;                                                                    \
-                const bool sure_pass = lhs < rhs - band, sure_fail = lhs > rhs + band;                                 \
-                bool flat = sure_pass;                                                                                 \
-                const bool unsure = ok && !sure_pass && !sure_fail;                                                    \
-                if (__ballot(unsure) != 0) {                                                                           \
-                    if (unsure) {                                                                                      \
-                        const double dt = dot(g0, dir / sqrt(d2)); /* NaN at d2 == 0: rejected as in the reference */ \
-                        flat = fabs(dt) <= thr;                                                                        \
-                    }                                                                                                  \
-                }                                                                                                      \
-                ok = ok && flat;                                                                                       \
+        pend = true;                                                                                                   \
+        while (cbase >= i_end) {                                                                                       \
+            qbase += 64;                                                                                               \
+            if (qbase >= Ktot || voff >= v_hi) { pend = false; break; }                                                \
+            const int qi = qbase + lane;                                                                               \
+            uint32_t cnt = 0;                                                                                          \
+            g_cs = 0;                                                                                                  \
+            if (qi < Ktot) {                                                                                           \
+                const int ix = R.cx0 + qi % kx, iy = R.cy0 + (qi / kx) % ky, iz = R.cz0 + qi / (kx * ky);             \
+                const uint32_t b = (uint32_t)((iz * tp.g.ny + iy) * tp.g.nx + ix);                                     \
+                g_cs = cell_start[b];                                                                                  \
+                cnt = cell_start[b + 1] - g_cs;                                                                        \
             }                                                                                                          \
-            if (ok) {                                                                                                  \
-                ax += __double_as_longlong(row[6]); ay += __double_as_longlong(row[7]); az += __double_as_longlong(row[8]); \
-                am++;                                                                                                  \
-                if (TAP) {                                                                                             \
-                    const unsigned long long ts = atomicAdd(tp.tap_n, 1ull);                                           \
-                    if ((int64_t)ts < tp.tap_cap) { tp.tap_key[ts] = (unsigned long long)__double_as_longlong(row[9]); tp.tap_pix[ts] = p; } \
-                }                                                                                                      \
-            }                                                                                                          \
+            uint32_t incl = cnt;                                                                                       \
+            for (int off = 1; off < 64; off <<= 1) { const uint32_t yy = __shfl_up(incl, off); if (lane >= off) incl += yy; } \
+            g_pre = incl - cnt;                                                                                        \
+            const unsigned int tot = (unsigned int)__builtin_amdgcn_readlane((int)incl, 63);                          \
+            const unsigned int g_lo = voff, g_hi = voff + tot;                                                         \
+            voff = g_hi;                                                                                               \
+            cbase = 0; i_end = 0;                                                                                      \
+            if (g_hi <= v_lo || g_lo >= v_hi) continue;                                                                \
+            cbase = (v_lo > g_lo ? v_lo : g_lo) - g_lo; i_end = (v_hi < g_hi ? v_hi : g_hi) - g_lo;                     \
         }                                                                                                              \
-        __builtin_amdgcn_wave_barrier();                                                                               \
-        sel_n = 0;                                                                                                     \
+        if (pend) {                                                                                                    \
+            const unsigned int i = cbase + (unsigned int)lane;                                                         \
+            p_has = i < i_end;                                                                                         \
+            int j = 0; /* the cell lane that owns list entry i: the largest j with pre_j <= i */                       \
+            for (int step = 32; step >= 1; step >>= 1) {                                                               \
+                const int cand = j + step;                                                                             \
+                const uint32_t pv = __shfl(g_pre, cand & 63);                                                          \
+                if (cand < 64 && pv <= i) j = cand;                                                                    \
+            }                                                                                                          \
+            p_r = __shfl(g_cs, j) + (i - __shfl(g_pre, j));                                                            \
+            if (p_has) {                                                                                               \
+                p0 = rec.f[p_r]; p1 = rec.f[cap + p_r]; p2 = rec.f[2 * cap + p_r];                                     \
+                p3 = rec.f[3 * cap + p_r]; p4 = rec.f[4 * cap + p_r]; p5 = rec.f[5 * cap + p_r];                       \
+                p6 = rec.f[6 * cap + p_r]; p7 = rec.f[7 * cap + p_r]; p8 = rec.f[8 * cap + p_r];                       \
+                if (TAP) p_key = rec.key[p_r];                                                                         \
+            }                                                                                                          \
+            cbase += 64;                                                                                               \
+        }                                                                                                              \
     }
-    unsigned int voff = 0;
-    for (int qbase = 0; qbase < Ktot && voff < v_hi; qbase += 64) {
-        const int qi = qbase + lane;
-        uint32_t cs = 0, cnt = 0;
-        if (qi < Ktot) {
-            const int ix = cx0 + qi % kx, iy = cy0 + (qi / kx) % ky, iz = cz0 + qi / (kx * ky);
-            const uint32_t b = (uint32_t)((iz * tp.g.ny + iy) * tp.g.nx + ix);
-            cs = cell_start[b];
-            cnt = cell_start[b + 1] - cs;
-        }
-        uint32_t incl = cnt;
-        for (int off = 1; off < 64; off <<= 1) { const uint32_t yy = __shfl_up(incl, off); if (lane >= off) incl += yy; }
-        const uint32_t pre = incl - cnt;
-        const unsigned int tot = (unsigned int)__builtin_amdgcn_readlane((int)incl, 63);
-        const unsigned int g_lo = voff, g_hi = voff + tot;
-        voff = g_hi;
-        if (g_hi <= v_lo || g_lo >= v_hi) continue;
-        const unsigned int i_begin = (v_lo > g_lo ? v_lo : g_lo) - g_lo, i_end = (v_hi < g_hi ? v_hi : g_hi) - g_lo;
-        for (unsigned int cbase = i_begin; cbase < i_end; cbase += 64) {
-            const unsigned int i = cbase + (unsigned int)lane;
-            const bool has = i < i_end;
-            int j = 0;  // the cell lane that owns list entry i: the largest j with pre_j <= i
-            for (int step = 32; step >= 1; step >>= 1) {
-                const int cand = j + step;
-                const uint32_t pv = __shfl(pre, cand & 63);
-                if (cand < 64 && pv <= i) j = cand;
-            }
-            const uint32_t r = __shfl(cs, j) + (i - __shfl(pre, j));
+    { const unsigned long long t0 = DSTAMP(); DEP_ISSUE() st_issue += DSTAMP() - t0; }
+    while (pend || sel_n > 0) {
+        if (pend) {
+            const unsigned long long t0 = DSTAMP();
+            // the pending group: keep what lies within rmax of the cluster's bounding box (a hitpoint of the cluster
+            // can only accept such records), compact it into the staging rows, and start the loads of the next group
             bool in = false;
-            double qx = 0.0, qy = 0.0, qz = 0.0;
-            if (has) {
-                qx = rec.f[r]; qy = rec.f[cap + r]; qz = rec.f[2 * cap + r];
-                // within rmax of the cluster's bounding box (a hitpoint of the cluster can only accept such records)
-                const double ex = fmax(fmax(bx0 - qx, qx - bx1), 0.0), ey = fmax(fmax(by0 - qy, qy - by1), 0.0), ez = fmax(fmax(bz0 - qz, qz - bz1), 0.0);
+            if (p_has) {
+                const double ex = fmax(fmax(R.bx0 - p0, p0 - R.bx1), 0.0), ey = fmax(fmax(R.by0 - p1, p1 - R.by1), 0.0), ez = fmax(fmax(R.bz0 - p2, p2 - R.bz1), 0.0);
                 in = ex * ex + ey * ey + ez * ez <= rmax2;
             }
-            const unsigned long long m = __ballot(in);
-            const int cnt_in = __popcll(m);
-            if (sel_n + cnt_in > 64) DEP_PROCESS()
+            const unsigned long long m = ballot64(in);
             if (in) {
                 double* row = s_row[wv][sel_n + __popcll(m & lt_mask)];
-                row[0] = qx; row[1] = qy; row[2] = qz;
-                row[3] = rec.f[3 * cap + r]; row[4] = rec.f[4 * cap + r]; row[5] = rec.f[5 * cap + r];
-                row[6] = __longlong_as_double(fx_fix(rec.f[6 * cap + r], fx_scale, clamped));
-                row[7] = __longlong_as_double(fx_fix(rec.f[7 * cap + r], fx_scale, clamped));
-                row[8] = __longlong_as_double(fx_fix(rec.f[8 * cap + r], fx_scale, clamped));
-                if (TAP) row[9] = __longlong_as_double((long long)rec.key[r]);
+                row[0] = p0; row[1] = p1; row[2] = p2; row[3] = p3; row[4] = p4; row[5] = p5;
+                row[6] = __longlong_as_double(fx_fix(p6, fx_scale, clamped));
+                row[7] = __longlong_as_double(fx_fix(p7, fx_scale, clamped));
+                row[8] = __longlong_as_double(fx_fix(p8, fx_scale, clamped));
+                if (TAP) row[ROW - 1] = __longlong_as_double((long long)p_key);
             }
-            sel_n += cnt_in;
+            sel_n += __popcll(m);
+            const unsigned long long t1 = DSTAMP();
+            DEP_ISSUE()
+            if (STAMPS) { st_append += t1 - t0; st_issue += DSTAMP() - t1; }
+            if (sel_n == 0) continue;
         }
+        const unsigned long long tp0 = DSTAMP();
+        // every hitpoint against the sel_n staged records: the search filter of src/kdtree.h:123-127 (its |cos| does
+        // not depend on the orientation of the normal) and the acceptance test of src/stochastic_ppm.h:441-445
+        __builtin_amdgcn_wave_barrier();
+        c_sel += (unsigned int)sel_n; c_pairs += (unsigned long long)sel_n * R.n_inc; c_round++;
+        const int sel_u = __builtin_amdgcn_readfirstlane(sel_n);
+        for (int ti = 0; ti < sel_u; ti++) {
+            const double* row = s_row[wv][ti];
+            const d3 g0 = mk(row[3], row[4], row[5]);
+            const d3 qq = mk(row[0], row[1], row[2]);
+            bool ok[DEP_H];
+            bool unsure = false;
+#pragma unroll
+            for (int h = 0; h < DEP_H; h++) {  // fast path (fused)
+                const d3 dir = mk(t.x[h], t.y[h], t.z[h]) - qq;
+                const double d2f = fma(dir.z, dir.z, fma(dir.y, dir.y, dir.x * dir.x));
+                const double ndf = fma(hn[h].z, g0.z, fma(hn[h].y, g0.y, hn[h].x * g0.x));
+                const double s1f = fma(g0.z, dir.z, fma(g0.y, dir.y, g0.x * dir.x));
+                const double lhs = s1f * s1f;
+                const bool in_d = d2f < lim_lo[h], out_d = d2f > lim_hi[h];     // both false: too close to call
+                const bool in_n = ndf > 1e-3 + 1e-13, out_n = ndf < 1e-3 - 1e-13;
+                const bool in_f = lhs < thr2_lo * d2f, out_f = lhs > thr2_hi * d2f;
+                ok[h] = in_d && in_n && in_f;
+                unsure = unsure || (inc[h] && !(out_d || out_n || out_f) && !ok[h]);
+            }
+            if (ballot64(unsure) != 0ull) {
+                // the reference's operation order for this record (every hitpoint: the result replaces the fast one)
+#pragma unroll
+                for (int h = 0; h < DEP_H; h++) {
+                    const d3 dir = mk(t.x[h], t.y[h], t.z[h]) - qq;
+                    const double d2 = len2(dir);
+                    bool o = inc[h] && (d2 < tp.gather_r2) && (d2 <= t.r2[h]) && (dot(hn[h], g0) > 1e-3);
+                    const double s1 = dot(g0, dir);
+                    const double l2 = s1 * s1, rhs = thr * thr * d2;
+                    const double band = rhs * band_rel;
+                    bool flat = l2 < rhs - band;
+                    if (o && !flat && !(l2 > rhs + band)) {
+                        const double dt = dot(g0, dir / sqrt(d2));  // NaN at d2 == 0: rejected as in the reference
+                        flat = fabs(dt) <= thr;
+                    }
+                    ok[h] = o && flat;
+                }
+            }
+            bool any_ok = false;
+#pragma unroll
+            for (int h = 0; h < DEP_H; h++) any_ok = any_ok || ok[h];
+            if (any_ok) {
+                const long long fx = __double_as_longlong(row[6]), fy = __double_as_longlong(row[7]), fz = __double_as_longlong(row[8]);
+#pragma unroll
+                for (int h = 0; h < DEP_H; h++) {
+                    if (ok[h]) {
+                        ax[h] += fx; ay[h] += fy; az[h] += fz; am[h]++;
+                        if (TAP) {
+                            const unsigned long long ts = atomicAdd(tp.tap_n, 1ull);
+                            if ((int64_t)ts < tp.tap_cap) { tp.tap_key[ts] = (unsigned long long)__double_as_longlong(row[ROW - 1]); tp.tap_pix[ts] = t.p[h]; }
+                        }
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        sel_n = 0;
+        st_process += DSTAMP() - tp0;
     }
-    if (sel_n > 0) DEP_PROCESS()
-#undef DEP_PROCESS
-    if (am > 0) {
-        atomicAdd((unsigned long long*)hp.dep + p, (unsigned long long)ax);
-        atomicAdd((unsigned long long*)hp.dep + (size_t)P + p, (unsigned long long)ay);
-        atomicAdd((unsigned long long*)hp.dep + 2 * (size_t)P + p, (unsigned long long)az);
-        atomicAdd((unsigned long long*)hp.dep + 3 * (size_t)P + p, (unsigned long long)am);
+#undef DEP_ISSUE
+    const unsigned long long tf0 = DSTAMP();
+    unsigned int c_acc = 0;
+#pragma unroll
+    for (int h = 0; h < DEP_H; h++) {
+        if (am[h] > 0) {
+            atomicAdd((unsigned long long*)hp.dep + t.p[h], (unsigned long long)ax[h]);
+            atomicAdd((unsigned long long*)hp.dep + (size_t)P + t.p[h], (unsigned long long)ay[h]);
+            atomicAdd((unsigned long long*)hp.dep + 2 * (size_t)P + t.p[h], (unsigned long long)az[h]);
+            atomicAdd((unsigned long long*)hp.dep + 3 * (size_t)P + t.p[h], (unsigned long long)am[h]);
+        }
+        c_acc += (unsigned int)am[h];
     }
-    if (__ballot(clamped) != 0 && lane == 0) err[6] = 1;
-    unsigned int c_acc = (unsigned int)am;
+    if (ballot64(clamped) != 0ull && lane == 0) err[6] = 1;
     for (int off = 32; off > 0; off >>= 1) c_acc += __shfl_down(c_acc, off);
     if (lane == 0) {
         if (c_pairs) atomicAdd(&counters[3], c_pairs);
@@ -275,7 +414,13 @@ __global__ void __launch_bounds__(256) k_deposit_tiles(HpArrays hp, RecArrays re
         atomicAdd(&counters[7], 1ull);
     }
     __builtin_amdgcn_wave_barrier();
+    st_flush += DSTAMP() - tf0;
     }  // next item
+    if (STAMPS && lane == 0) {
+        atomicAdd(&counters[16], st_setup); atomicAdd(&counters[17], st_count); atomicAdd(&counters[18], st_issue);
+        atomicAdd(&counters[19], st_append); atomicAdd(&counters[20], st_process); atomicAdd(&counters[21], st_flush);
+    }
+#undef DSTAMP
 }
 
 // End-of-pass update of the per-pass rule, src/stochastic_ppm.h:721-741, from the (summed) deposits; clears them.

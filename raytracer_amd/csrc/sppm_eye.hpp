@@ -223,9 +223,12 @@ __device__ __forceinline__ void eye_pixel(const DevScene& sc, const EyeParams& e
     eye_pixel_end<RNG, COMMIT>(ep, hp, out, e);
 }
 
+#ifndef EYE_WAVES
+#define EYE_WAVES 3
+#endif
 // One thread per pixel, one XorShift stream per (pass, image index).
 template <int GRID>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) k_eye_pass(DevScene sc, EyeParams ep, HpArrays hp, HpArrays out, unsigned long long* __restrict__ counters)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EYE_WAVES, EYE_WAVES))) k_eye_pass(DevScene sc, EyeParams ep, HpArrays hp, HpArrays out, unsigned long long* __restrict__ counters)
 {
     STAGE_SCENE_T(sc, GRID);
     int t = blockIdx.x * blockDim.x + threadIdx.x;

@@ -26,6 +26,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <mutex>
 #include <random>
 #include <string>
@@ -54,7 +55,16 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
         if (e_ != hipSuccess) return fail(SPPM_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
-#define NBUF 3
+#ifndef NBUF
+#define NBUF 4  // record buffers in the ring: the one being gathered and up to NBUF - 1 traced ahead
+#endif
+// Tracer streams.  The device gives a process FOUR hardware queues (GPU_MAX_HW_QUEUES); streams beyond that share
+// one, and a kernel waits behind whatever runs on the stream it shares a queue with.  With a stream per record buffer
+// (round 1: 3 + eye + context = 5) the context's stream shared its queue with one of the tracer streams, and every
+// NBUF-th pass its kernels sat behind a 4-10 ms tracer launch (profiles/r02_pass_gaps_before.txt: one gap in three
+// of 1.5-7 ms).  So: context, eye, and TWO tracer streams that the buffers of the ring take in turn (NBUF is even).
+#define NTS 2
+#define TSTREAM(c, b) ((c)->tstream[(b) % NTS])
 struct sppm_ctx {
     sppm_config cfg;
     int device;
@@ -93,7 +103,14 @@ struct sppm_ctx {
     // What an eye pass writes (hitpoint geometry, valid flags, direct term, tile order, bounding box) exists
     // twice: the eye pass of pass i+1 fills the other view on its own stream while the gather of pass i still
     // reads this one.  Radii, counts and flux are shared (an eye pass only initialises them for new pixels).
-    HpArrays view[2]; int32_t* d_order_v[2]; unsigned long long* d_hp_bb_v[2]; uint8_t* d_near_v[2]; uint8_t* d_near; int cur_view;
+    HpArrays view[2]; uint8_t* d_near_v[2]; uint8_t* d_near; int cur_view;
+    // The tile order (and the bounding box made with it) of an eye pass, in a ring of three buffers (in use, made
+    // last, being made); view_chain[v]: the buffer of the eye pass that wrote view v.  (Using the order of the pass
+    // BEFORE, so that the sort chain need not finish between two gathers, was tried: any permutation is a valid order,
+    // but the ~5 % of the pixels that look through the glass sphere land somewhere else every pass, their tiles of a
+    // stale order are scattered over the scene, and the gather took four times as long.)
+    int32_t* d_order_r[3]; unsigned long long* d_hp_bb_r[3]; hipEvent_t ev_order[3];
+    int chain_n, view_chain[2];
     hipStream_t eye_stream; hipEvent_t ev_eye_done, ev_eye_go;
     struct { int valid, pass; } pre_eye;  // an eye pass computed ahead of its call
     int last_eye_pass;
@@ -112,9 +129,11 @@ struct sppm_ctx {
     // rec_u / d_rec_count / d_trace_next above always alias buffer `cur`.
     RecArrays rec_buf[NBUF]; unsigned long long* d_rec_count_buf[NBUF]; unsigned long long* d_trace_next_buf[NBUF];
     int cur;
-    hipStream_t tstream[NBUF];
+    hipStream_t tstream[NTS];
     hipEvent_t ev_traced[NBUF], ev_free[NBUF];
-    struct Pre { int valid, buf, pass; int64_t first, count; } pre, pre2;  // batches traced ahead of their photon_pass call: the next one, and (steady state) the one after
+    struct Pre { int valid, buf, pass; int64_t first, count; } pre;  // a batch traced ahead through sppm_look_ahead
+    std::deque<Pre> ahead;  // sppm_photon_pass: the batches traced ahead, next first, in ring buffers cur+1, cur+2, ...
+    int ahead_depth;  // batches traced ahead of their photon_pass call: the next one, and (steady state) the one after
     int prefetch;
     int32_t* d_err;                  // 4
     uint32_t *d_cell_cnt, *d_cell_start, *d_cursor, *d_block_sum, *d_total, *d_rec_bucket;  // alias bins[cur]
@@ -155,7 +174,7 @@ static int grow(sppm_ctx* c, T** p, int64_t* cap, int64_t need)
 {
     if (*cap >= need) return 0;
     HIPCHK(hipStreamSynchronize(c->stream));
-    for (int b = 0; b < NBUF; b++) if (c->tstream[b]) HIPCHK(hipStreamSynchronize(c->tstream[b]));
+    for (int b = 0; b < NTS; b++) if (c->tstream[b]) HIPCHK(hipStreamSynchronize(c->tstream[b]));
     if (*p) hipFree(*p);
     *p = nullptr; *cap = 0;
     void* q = nullptr;
@@ -355,8 +374,10 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
     c->rec_first = c->rec_end = 0;
     c->photons_applied = 0;
     c->ns = n_spheres;
-    for (int b = 0; b < NBUF; b++) { c->tstream[b] = nullptr; c->ev_traced[b] = nullptr; c->ev_free[b] = nullptr; }
-    c->eye_stream = nullptr; c->ev_eye_done = c->ev_eye_go = nullptr; c->d_order_v[0] = c->d_order_v[1] = nullptr; c->d_hp_bb_v[0] = c->d_hp_bb_v[1] = nullptr;
+    for (int b = 0; b < NTS; b++) c->tstream[b] = nullptr;
+    for (int b = 0; b < NBUF; b++) { c->ev_traced[b] = nullptr; c->ev_free[b] = nullptr; }
+    c->eye_stream = nullptr; c->ev_eye_done = c->ev_eye_go = nullptr; for (int k = 0; k < 3; k++) { c->d_order_r[k] = nullptr; c->d_hp_bb_r[k] = nullptr; c->ev_order[k] = nullptr; }
+    c->chain_n = 0; c->view_chain[0] = c->view_chain[1] = -1;
     c->tap_cap = 0; c->d_tap_key = nullptr; c->d_tap_pix = nullptr; c->d_tap_n = nullptr;
     c->sampler = cfg->sampler; c->eye_eng.seed(cfg->seed_eye); c->lens_eng.seed(cfg->seed_lens); c->d_u_lens = nullptr; c->u_lens_cap = 0;
     c->d_u_eye = c->d_u_ph = nullptr; c->u_eye_cap = c->u_ph_cap = 0; c->u_eye_len = 0; c->d_eye_cnt = nullptr; c->d_ph_start = c->d_ph_consumed = nullptr;
@@ -419,10 +440,13 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
     c->view[0] = c->hp; c->view[1] = c->hp; c->cur_view = 0; c->pre_eye.valid = 0; c->last_eye_pass = -1;
     TRY(dev_alloc(c, &c->view[1].pos, 3 * P)); TRY(dev_alloc(c, &c->view[1].nrm, 3 * P)); TRY(dev_alloc(c, &c->view[1].w, 3 * P));
     TRY(dev_alloc(c, &c->view[1].ld, 3 * P)); TRY(dev_alloc(c, &c->view[1].dist, P)); TRY(dev_alloc(c, &c->view[1].obj, P)); TRY(dev_alloc(c, &c->view[1].valid, P));
+    // (stream priorities for the look-ahead streams were tried: the run hung until its time limit; not used)
     if (hipStreamCreateWithFlags(&c->eye_stream, hipStreamNonBlocking) != hipSuccess) { sppm_destroy(c); return fail(SPPM_ERR_HIP, "creating the eye stream failed"); }
     if (hipEventCreateWithFlags(&c->ev_eye_done, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_eye_go, hipEventDisableTiming) != hipSuccess) {
         sppm_destroy(c); return fail(SPPM_ERR_HIP, "creating events failed");
     }
+    for (int k = 0; k < 3; k++)
+        if (hipEventCreateWithFlags(&c->ev_order[k], hipEventDisableTiming) != hipSuccess) { sppm_destroy(c); return fail(SPPM_ERR_HIP, "creating events failed"); }
     // record buffers: one batch of photons, ~2.6 records per photon on the Cornell scene; 8x head room
     c->batch_photons = env_i64("SPPM_BATCH_PHOTONS", c->gather_mode ? (1 << 20) : (1 << 18));
     if (c->batch_photons < 1024) c->batch_photons = 1024;
@@ -435,12 +459,13 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
         TRY(dev_alloc(c, &c->d_rec_count_buf[b], 1)); TRY(dev_alloc(c, &c->d_trace_next_buf[b], 1));
     }
     c->cur = 0; c->rec_u = c->rec_buf[0]; c->d_rec_count = c->d_rec_count_buf[0]; c->d_trace_next = c->d_trace_next_buf[0];  // bins[] aliases: set_cur below, once they exist
-    c->pre.valid = 0; c->pre2.valid = 0;
+    c->pre.valid = 0;
+    c->ahead_depth = (int)std::max<int64_t>(1, std::min<int64_t>(NBUF - 1, env_i64("SPPM_AHEAD", NBUF - 1)));
     c->prefetch = (int)env_i64("SPPM_PREFETCH", 1);
     if (c->sampler == 1) {
         c->prefetch = 0;  // a pass's photon stream offsets exist only once its photon pass has begun
     }
-    for (int b = 0; b < NBUF; b++)
+    for (int b = 0; b < NTS; b++)
         if (hipStreamCreateWithFlags(&c->tstream[b], hipStreamNonBlocking) != hipSuccess) { sppm_destroy(c); return fail(SPPM_ERR_HIP, "creating the trace streams failed"); }
     for (int b = 0; b < NBUF; b++)
         if (hipEventCreateWithFlags(&c->ev_traced[b], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_free[b], hipEventDisableTiming) != hipSuccess) {
@@ -483,9 +508,11 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
         }
         c->n_own_pix = (int)own.size();
         c->n_owned = (c->n_own_pix + 63) / 64;  // virtual tiles of 64 hitpoints
-        TRY(dev_alloc(c, &c->d_own_pix, own.size(), false)); TRY(dev_alloc(c, &c->d_order_v[0], own.size(), false)); TRY(dev_alloc(c, &c->d_order_v[1], own.size(), false)); c->d_order = c->d_order_v[0];
+        TRY(dev_alloc(c, &c->d_own_pix, own.size(), false)); for (int k = 0; k < 3; k++) TRY(dev_alloc(c, &c->d_order_r[k], own.size(), false));
+        c->d_order = c->d_order_r[0];
         TRY(dev_alloc(c, &c->d_hp_keys, own.size(), false)); TRY(dev_alloc(c, &c->d_hp_keys_out, own.size(), false));
-        TRY(dev_alloc(c, &c->d_hp_bb_v[0], 6)); TRY(dev_alloc(c, &c->d_hp_bb_v[1], 6)); c->d_hp_bb = c->d_hp_bb_v[0];
+        for (int k = 0; k < 3; k++) TRY(dev_alloc(c, &c->d_hp_bb_r[k], 6));
+        c->d_hp_bb = c->d_hp_bb_r[0];
         TRY(dev_alloc(c, &c->d_near_v[0], (size_t)NEAR_DIM * NEAR_DIM * NEAR_DIM)); TRY(dev_alloc(c, &c->d_near_v[1], (size_t)NEAR_DIM * NEAR_DIM * NEAR_DIM)); c->d_near = c->d_near_v[0];
         TRY(dev_alloc(c, &c->d_own_mask, P, false));  // every byte is written by the upload below
         std::vector<uint8_t> mask(P, 0);  // lives until the stream synchronisation at the end of sppm_create
@@ -521,13 +548,14 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
 extern "C" int sppm_destroy(sppm_ctx* c)
 {
     if (!c) return SPPM_OK;
-    for (int b = 0; b < NBUF; b++) if (c->tstream[b]) hipStreamSynchronize(c->tstream[b]);
+    for (int b = 0; b < NTS; b++) if (c->tstream[b]) hipStreamSynchronize(c->tstream[b]);
     if (c->eye_stream) { hipStreamSynchronize(c->eye_stream); hipStreamDestroy(c->eye_stream); }
+    for (int k = 0; k < 3; k++) if (c->ev_order[k]) hipEventDestroy(c->ev_order[k]);
     if (c->ev_eye_done) hipEventDestroy(c->ev_eye_done);
     if (c->ev_eye_go) hipEventDestroy(c->ev_eye_go);
     hipStreamSynchronize(c->stream);
     for (int b = 0; b < NBUF; b++) { if (c->ev_traced[b]) hipEventDestroy(c->ev_traced[b]); if (c->ev_free[b]) hipEventDestroy(c->ev_free[b]); }
-    for (int b = 0; b < NBUF; b++) if (c->tstream[b]) hipStreamDestroy(c->tstream[b]);
+    for (int b = 0; b < NTS; b++) if (c->tstream[b]) hipStreamDestroy(c->tstream[b]);
     for (auto& e : c->ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (auto& e : c->ev_trace) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (void* p : c->allocs) hipFree(p);
@@ -765,6 +793,8 @@ static int eye_launch(sppm_ctx* c, int32_t pass, hipStream_t st)
     ep.pass = pass; ep.seed_eye = c->cfg.seed_eye; ep.initial_r2 = c->cfg.initial_radius2; ep.double_nee = c->cfg.double_nee;
     ep.u = nullptr; ep.u_len = 0; ep.cnt = nullptr; ep.off = nullptr; ep.total = nullptr; ep.hcnt = nullptr; ep.hoff = nullptr;
     ep.seed_lens = c->cfg.seed_lens; ep.lens_u = nullptr;
+    // the order chain that last read this view's positions must be done before the view is written again
+    if (c->view_chain[nv] >= 0) HIPCHK(hipStreamWaitEvent(st, c->ev_order[c->view_chain[nv]], 0));
     if (c->algo == 1) {
         int rc = ppm_eye_emit(c, nv, st);
         if (rc) return rc;
@@ -780,14 +810,18 @@ static int eye_launch(sppm_ctx* c, int32_t pass, hipStream_t st)
         HIPCHK(hipGetLastError());
     }
     if (c->gather_mode && c->n_own_pix > 0) {
-        // re-form the gather tiles: sort this rank's hitpoints along a Morton curve of their positions
+        // re-form the gather tiles: sort this rank's hitpoints along a Morton curve of their positions, into the next
+        // of the three order buffers
+        const int slot = c->chain_n % 3;
+        c->chain_n++;
+        c->view_chain[nv] = slot;
         // bounding box seed: min slots all ones, max slots zero (ordered-int doubles); two memsets, nothing host-sourced
-        HIPCHK(hipMemsetAsync(c->d_hp_bb_v[nv], 0xFF, 3 * sizeof(unsigned long long), st));
-        HIPCHK(hipMemsetAsync(c->d_hp_bb_v[nv] + 3, 0x00, 3 * sizeof(unsigned long long), st));
-        hipLaunchKernelGGL(k_hp_bbox, dim3(std::min(nblk(c->n_own_pix, 256), 512)), dim3(256), 0, st, c->view[nv], c->d_own_pix, c->n_own_pix, c->d_hp_bb_v[nv]);
-        hipLaunchKernelGGL(k_hp_sortkeys, dim3(nblk(c->n_own_pix, 256)), dim3(256), 0, st, c->view[nv], c->d_own_pix, c->n_own_pix, c->d_hp_bb_v[nv], c->d_hp_keys);
+        HIPCHK(hipMemsetAsync(c->d_hp_bb_r[slot], 0xFF, 3 * sizeof(unsigned long long), st));
+        HIPCHK(hipMemsetAsync(c->d_hp_bb_r[slot] + 3, 0x00, 3 * sizeof(unsigned long long), st));
+        hipLaunchKernelGGL(k_hp_bbox, dim3(std::min(nblk(c->n_own_pix, 256), 512)), dim3(256), 0, st, c->view[nv], c->d_own_pix, c->n_own_pix, c->d_hp_bb_r[slot]);
+        hipLaunchKernelGGL(k_hp_sortkeys, dim3(nblk(c->n_own_pix, 256)), dim3(256), 0, st, c->view[nv], c->d_own_pix, c->n_own_pix, c->d_hp_bb_r[slot], c->d_hp_keys);
         HIPCHK(hipGetLastError());
-        HIPCHK(rocprim::radix_sort_pairs(c->d_sort_tmp, c->sort_tmp_bytes, c->d_hp_keys, c->d_hp_keys_out, c->d_own_pix, c->d_order_v[nv],
+        HIPCHK(rocprim::radix_sort_pairs(c->d_sort_tmp, c->sort_tmp_bytes, c->d_hp_keys, c->d_hp_keys_out, c->d_own_pix, c->d_order_r[slot],
                                          (size_t)c->n_own_pix, 0, 3 * MORTON_BITS + 1, st));
         if (c->own_pending) {
             // Spatial ownership: this rank keeps positions [rank*P/N, (rank+1)*P/N) of the order just made
@@ -797,33 +831,42 @@ static int eye_launch(sppm_ctx* c, int32_t pass, hipStream_t st)
             const int64_t lo = (int64_t)c->tile_first * c->P / c->tile_stride, hi = (int64_t)(c->tile_first + 1) * c->P / c->tile_stride;
             const int n = (int)(hi - lo);
             if (n > 0) {
-                HIPCHK(hipMemcpyAsync(c->d_own_pix, c->d_order_v[nv] + lo, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
-                HIPCHK(hipMemcpyAsync(c->d_order_v[nv], c->d_own_pix, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
+                HIPCHK(hipMemcpyAsync(c->d_own_pix, c->d_order_r[slot] + lo, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
+                HIPCHK(hipMemcpyAsync(c->d_order_r[slot], c->d_own_pix, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
             }
             HIPCHK(hipMemsetAsync(c->d_own_mask, 0, (size_t)c->P, st));
             if (n > 0) hipLaunchKernelGGL(k_mask_from_list, dim3(nblk(n, 256)), dim3(256), 0, st, c->d_own_pix, n, c->d_own_mask);
             c->n_own_pix = n; c->n_owned = (n + 63) / 64; c->own_pending = 0;
             if (n > 0) {  // the bounding box of what this rank keeps
-                HIPCHK(hipMemsetAsync(c->d_hp_bb_v[nv], 0xFF, 3 * sizeof(unsigned long long), st));
-                HIPCHK(hipMemsetAsync(c->d_hp_bb_v[nv] + 3, 0x00, 3 * sizeof(unsigned long long), st));
-                hipLaunchKernelGGL(k_hp_bbox, dim3(std::min(nblk(n, 256), 512)), dim3(256), 0, st, c->view[nv], c->d_own_pix, n, c->d_hp_bb_v[nv]);
+                HIPCHK(hipMemsetAsync(c->d_hp_bb_r[slot], 0xFF, 3 * sizeof(unsigned long long), st));
+                HIPCHK(hipMemsetAsync(c->d_hp_bb_r[slot] + 3, 0x00, 3 * sizeof(unsigned long long), st));
+                hipLaunchKernelGGL(k_hp_bbox, dim3(std::min(nblk(n, 256), 512)), dim3(256), 0, st, c->view[nv], c->d_own_pix, n, c->d_hp_bb_r[slot]);
             }
             HIPCHK(hipGetLastError());
         }
         if (c->tile_stride > 1) {  // which coarse cells lie near this rank's hitpoints (drops far records, k_mark_near)
             HIPCHK(hipMemsetAsync(c->d_near_v[nv], 0, (size_t)NEAR_DIM * NEAR_DIM * NEAR_DIM, st));
-            hipLaunchKernelGGL(k_mark_near, dim3(nblk(c->n_own_pix, 256)), dim3(256), 0, st, c->view[nv], c->d_own_pix, c->n_own_pix, c->d_hp_bb_v[nv], reach_of(c), c->cfg.gather_radius2, c->d_near_v[nv]);
+            hipLaunchKernelGGL(k_mark_near, dim3(nblk(c->n_own_pix, 256)), dim3(256), 0, st, c->view[nv], c->d_own_pix, c->n_own_pix, c->d_hp_bb_r[slot], reach_of(c), c->cfg.gather_radius2, c->d_near_v[nv]);
             HIPCHK(hipGetLastError());
         }
+        HIPCHK(hipEventRecord(c->ev_order[slot], st));
     }
     return 0;
 }
 
-static void flip_view(sppm_ctx* c)
+// the view an eye pass has written becomes the current one; what follows on the context's stream is ordered behind
+// the tile order made with it
+static int flip_view(sppm_ctx* c)
 {
     c->cur_view ^= 1;
-    c->hp = c->view[c->cur_view]; c->d_order = c->d_order_v[c->cur_view]; c->d_hp_bb = c->d_hp_bb_v[c->cur_view]; c->d_near = c->d_near_v[c->cur_view];
+    c->hp = c->view[c->cur_view]; c->d_near = c->d_near_v[c->cur_view];
+    const int own = c->view_chain[c->cur_view];
+    if (own >= 0) {
+        HIPCHK(hipStreamWaitEvent(c->stream, c->ev_order[own], 0));
+        c->d_order = c->d_order_r[own]; c->d_hp_bb = c->d_hp_bb_r[own];
+    }
     c->order_valid = 1;
+    return 0;
 }
 
 // Eye pass of pass+1 ahead of its call, on the eye stream, while the gather of `pass` runs: eye paths do not
@@ -850,7 +893,8 @@ extern "C" int sppm_eye_pass(sppm_ctx* c, int32_t pass)
         c->pre_eye.valid = 0;
         if (c->pre_eye.pass == pass) {  // computed ahead: order it before what follows on the context's stream
             HIPCHK(hipStreamWaitEvent(c->stream, c->ev_eye_done, 0));
-            flip_view(c);
+            int rcf = flip_view(c);
+            if (rcf) return rcf;
             c->last_eye_pass = pass;
             return SPPM_OK;
         }
@@ -858,7 +902,8 @@ extern "C" int sppm_eye_pass(sppm_ctx* c, int32_t pass)
     }
     int rc = eye_launch(c, pass, c->stream);
     if (rc) return rc;
-    flip_view(c);
+    rc = flip_view(c);
+    if (rc) return rc;
     c->last_eye_pass = pass;
     return SPPM_OK;
 }
@@ -910,7 +955,7 @@ extern "C" int sppm_trace(sppm_ctx* c, int32_t pass, int64_t first, int64_t coun
     if (c->cfg.photons_per_pass > 0 && first + count > c->cfg.photons_per_pass)
         return fail(SPPM_ERR_INVALID, "sppm_trace: photon range exceeds photons_per_pass");
     if (count == 0) return SPPM_OK;
-    if (c->pre2.valid) { int rc2 = discard_prefetch(c); if (rc2) return rc2; }
+    if (!c->ahead.empty()) { int rc2 = discard_prefetch(c); if (rc2) return rc2; }
     if (c->pre.valid && c->pre.pass == pass && c->pre.first == first && c->pre.count == count && c->rec_end == c->rec_first) {
         // traced ahead (sppm_look_ahead): order it before what follows and make its buffer the current one
         HIPCHK(hipStreamWaitEvent(c->stream, c->ev_traced[c->pre.buf], 0));
@@ -943,11 +988,11 @@ extern "C" int sppm_look_ahead(sppm_ctx* c, int32_t pass, int64_t first, int64_t
     const int nb = (c->cur + 1) % NBUF;
     // the other buffer is free once everything enqueued on the context's stream so far has run
     HIPCHK(hipEventRecord(c->ev_free[nb], c->stream));
-    HIPCHK(hipStreamWaitEvent(c->tstream[nb], c->ev_free[nb], 0));
-    HIPCHK(hipMemsetAsync(c->d_rec_count_buf[nb], 0, sizeof(unsigned long long), c->tstream[nb]));
-    rc = trace_into(c, nb, pass, first, count, c->tstream[nb]);
+    HIPCHK(hipStreamWaitEvent(TSTREAM(c, nb), c->ev_free[nb], 0));
+    HIPCHK(hipMemsetAsync(c->d_rec_count_buf[nb], 0, sizeof(unsigned long long), TSTREAM(c, nb)));
+    rc = trace_into(c, nb, pass, first, count, TSTREAM(c, nb));
     if (rc) return rc;
-    HIPCHK(hipEventRecord(c->ev_traced[nb], c->tstream[nb]));
+    HIPCHK(hipEventRecord(c->ev_traced[nb], TSTREAM(c, nb)));
     c->pre.valid = 1; c->pre.buf = nb; c->pre.pass = pass; c->pre.first = first; c->pre.count = count;
     if (pass == c->last_eye_pass + 1) { rc = eye_prefetch(c, pass); if (rc) return rc; }
     return SPPM_OK;
@@ -965,7 +1010,7 @@ extern "C" int sppm_look_ahead_rows(sppm_ctx* c, int32_t pass, int64_t first, in
     int rc = sppm_look_ahead(c, pass, first, count);
     if (rc) return rc;
     const int nb = count > 0 ? c->pre.buf : (c->cur + 1) % NBUF;
-    hipStream_t ts = c->tstream[nb];
+    hipStream_t ts = TSTREAM(c, nb);
     HIPCHK(hipMemsetAsync(c->d_rows_n, 0, sizeof(unsigned long long), ts));
     if (count > 0) {
         hipLaunchKernelGGL(k_pack_records, dim3(nblk(c->rec_buf[nb].cap, 4 * WAVE_ROWS)), dim3(256), 0, ts, c->rec_buf[nb], c->d_rec_count_buf[nb], d_rows, cap_rows, c->d_rows_n);
@@ -1370,15 +1415,26 @@ static int deposit_tiles(sppm_ctx* c)
     hipLaunchKernelGGL(k_sat_axis, dim3(nblk(g.ny * g.nz, 64)), dim3(64), 0, st, c->d_cell_tot, g.nx, g.ny, g.nz, 0);
     hipLaunchKernelGGL(k_sat_axis, dim3(nblk(g.nx * g.nz, 64)), dim3(64), 0, st, c->d_cell_tot, g.nx, g.ny, g.nz, 1);
     hipLaunchKernelGGL(k_sat_axis, dim3(nblk(g.nx * g.ny, 64)), dim3(64), 0, st, c->d_cell_tot, g.nx, g.ny, g.nz, 2);
-    hipLaunchKernelGGL(k_deposit_plan, dim3(nblk(c->n_owned, 4)), dim3(256), 0, st, c->hp, c->d_cell_tot, tp, (uint32_t)c->dep_chunk, c->d_items_raw, c->d_n_pieces, c->d_est);
-    hipLaunchKernelGGL(k_items_hist, dim3(nblk(c->n_owned, 256)), dim3(256), 0, st, c->d_items_raw, c->d_n_pieces, c->n_owned, c->d_item_q);
+    const int n_dep_tiles = (c->n_own_pix + DEP_TILE - 1) / DEP_TILE;  // DEP_H hitpoints per lane
+    hipLaunchKernelGGL(k_deposit_plan, dim3(nblk(n_dep_tiles, 4)), dim3(256), 0, st, c->hp, c->d_cell_tot, tp, n_dep_tiles, (uint32_t)c->dep_chunk, c->d_items_raw, c->d_n_pieces, c->d_est);
+    hipLaunchKernelGGL(k_items_hist, dim3(nblk(n_dep_tiles, 256)), dim3(256), 0, st, c->d_items_raw, c->d_n_pieces, n_dep_tiles, c->d_item_q);
     hipLaunchKernelGGL(k_items_bases, dim3(1), dim3(64), 0, st, c->d_item_q);
-    hipLaunchKernelGGL(k_items_scatter, dim3(nblk(c->n_owned, 256)), dim3(256), 0, st, c->d_items_raw, c->d_n_pieces, c->n_owned, c->d_item_q, c->d_items);
-    c->est_valid = 1; c->est_range = range;
-    const int blocks = std::max(1, std::min(nblk(c->n_owned, 4) * 4, (int)env_i64("SPPM_DEP_BLOCKS", 256 * 8)));
+    hipLaunchKernelGGL(k_items_scatter, dim3(nblk(n_dep_tiles, 256)), dim3(256), 0, st, c->d_items_raw, c->d_n_pieces, n_dep_tiles, c->d_item_q, c->d_items);
+    c->est_valid = 0;  // (the estimates of the ordered gather's plan are not made here)
+    const int blocks = std::max(1, std::min(nblk(n_dep_tiles, 4) * 4, (int)env_i64("SPPM_DEP_BLOCKS", 256 * (DEP_H == 1 ? 4 : 3))));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->timing) { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventRecord(e0, st)); }
-    if (c->tap_cap > 0)
+    const bool stamps = getenv("SPPM_STAMPS") != nullptr;
+    if (stamps) {
+        HIPCHK(hipMemsetAsync(c->d_counters + 16, 0, 6 * sizeof(unsigned long long), st));
+        hipLaunchKernelGGL((k_deposit_tiles<false, true>), dim3(blocks), dim3(256), 0, st, c->hp, BS.rec_s, BS.cell_start, tp, c->fx_scale, c->d_items, c->d_item_q, c->d_counters, c->d_err);
+        unsigned long long t[24];
+        HIPCHK(hipMemcpyAsync(t, c->d_counters, sizeof t, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        const double tot = (double)(t[16] + t[17] + t[18] + t[19] + t[20] + t[21]);
+        fprintf(stderr, "[sppm] deposit: items %llu, shares of wave cycles: setup %.1f%% count %.1f%% issue %.1f%% append(wait) %.1f%% process %.1f%% flush %.1f%%; grid %dx%dx%d\n", t[7],
+                100.0 * t[16] / tot, 100.0 * t[17] / tot, 100.0 * t[18] / tot, 100.0 * t[19] / tot, 100.0 * t[20] / tot, 100.0 * t[21] / tot, g.nx, g.ny, g.nz);
+    } else if (c->tap_cap > 0)
         hipLaunchKernelGGL(k_deposit_tiles<true>, dim3(blocks), dim3(256), 0, st, c->hp, BS.rec_s, BS.cell_start, tp, c->fx_scale, c->d_items, c->d_item_q, c->d_counters, c->d_err);
     else
         hipLaunchKernelGGL(k_deposit_tiles<false>, dim3(blocks), dim3(256), 0, st, c->hp, BS.rec_s, BS.cell_start, tp, c->fx_scale, c->d_items, c->d_item_q, c->d_counters, c->d_err);
@@ -1415,19 +1471,22 @@ static int64_t batch_size(const sppm_ctx* c, uint64_t applied)
     return n;
 }
 
-// drop a batch that was traced ahead but is not the one now asked for
+// drop the batches that were traced ahead but are not the ones now asked for
 static int discard_prefetch(sppm_ctx* c)
 {
-    for (sppm_ctx::Pre* q : {&c->pre, &c->pre2}) {
-        if (!q->valid) continue;
-        const int b = q->buf;
-        HIPCHK(hipStreamSynchronize(c->tstream[b]));
+    std::vector<sppm_ctx::Pre> all(c->ahead.begin(), c->ahead.end());
+    if (c->pre.valid) all.push_back(c->pre);
+    if (!all.empty() && getenv("SPPM_DEBUG")) fprintf(stderr, "[sppm] look-ahead dropped: %zu batches (first: pass %d photons %lld+%lld)\n", all.size(), all[0].pass, (long long)all[0].first, (long long)all[0].count);
+    for (const sppm_ctx::Pre& q : all) {
+        const int b = q.buf;
+        HIPCHK(hipStreamSynchronize(TSTREAM(c, b)));
         HIPCHK(hipMemsetAsync(c->d_rec_count_buf[b], 0, sizeof(unsigned long long), c->stream));
         HIPCHK(hipEventRecord(c->ev_free[b], c->stream));
         c->bins[b].binned = 0;
-        c->photons_traced -= (uint64_t)q->count;
-        q->valid = 0;
+        c->photons_traced -= (uint64_t)q.count;
     }
+    c->ahead.clear();
+    c->pre.valid = 0;
     return 0;
 }
 
@@ -1435,20 +1494,42 @@ static int discard_prefetch(sppm_ctx* c)
 // that last used the buffer is done
 static int launch_ahead(sppm_ctx* c, int buf, int32_t pass, int64_t first, int64_t count)
 {
-    HIPCHK(hipStreamWaitEvent(c->tstream[buf], c->ev_free[buf], 0));
-    int rc = trace_into(c, buf, pass, first, count, c->tstream[buf]);
+    HIPCHK(hipStreamWaitEvent(TSTREAM(c, buf), c->ev_free[buf], 0));
+    int rc = trace_into(c, buf, pass, first, count, TSTREAM(c, buf));
     if (rc) return rc;
-    if (c->gather_mode && c->n_owned > 0) { rc = bin_into(c, buf, grid_for(c, first, count), c->tstream[buf]); if (rc) return rc; }
-    HIPCHK(hipEventRecord(c->ev_traced[buf], c->tstream[buf]));
+    if (c->gather_mode && c->n_owned > 0) { rc = bin_into(c, buf, grid_for(c, first, count), TSTREAM(c, buf)); if (rc) return rc; }
+    HIPCHK(hipEventRecord(c->ev_traced[buf], TSTREAM(c, buf)));
     return 0;
 }
 
-// Photon pass in batches.  While the gather of batch k runs on the context's stream, the tracer
-// already fills the other record buffer with batch k+1 on its own stream -- across the end of the pass
-// too: photon paths do not depend on hitpoints, so the first batch of the NEXT pass is traced ahead on
-// the assumption that the caller will ask for the same photon range again (dropped if it does not).
-// The tracer's long tail (a few photons bounce hundreds of times inside the glass sphere) hides
-// behind the gather this way.
+// The batch expected after `cur`, given that the caller asked for photons [first, first + count) of `pass` and is
+// assumed to go on the same way: the rest of this call, then the same range of the next pass (SPPM) or the photons
+// that follow (classic PPM, one run fed in several calls).  `applied`: photons gathered once `cur` has been.
+static bool batch_after(const sppm_ctx* c, int64_t first, int64_t count, const sppm_ctx::Pre& cur, uint64_t applied, sppm_ctx::Pre* out)
+{
+    out->valid = 1; out->buf = -1;
+    const int64_t cur_end = cur.first + cur.count;
+    if (c->algo == 1) {  // consecutive photons of the one run; calls are assumed to stay `count` long
+        if (cur_end >= c->cfg.photons_per_pass) return false;
+        const bool same_call = (cur_end - first) % count != 0;
+        if (!same_call && !c->prefetch) return false;
+        const int64_t call_end = std::min<int64_t>(c->cfg.photons_per_pass, first + ((cur_end - first) / count + 1) * count);
+        out->pass = cur.pass; out->first = cur_end; out->count = std::min(batch_size(c, applied), call_end - cur_end);
+        return out->count > 0;
+    }
+    if (cur_end < first + count) { out->pass = cur.pass; out->first = cur_end; out->count = std::min(batch_size(c, applied), first + count - cur_end); return true; }
+    if (!c->prefetch) return false;
+    out->pass = cur.pass + 1; out->first = first; out->count = std::min(batch_size(c, applied), count);
+    return true;
+}
+
+// Photon pass in batches.  While the gather of a batch runs on the context's stream, the tracer already fills the
+// next record buffers of the ring with the batches expected after it, each on a stream of its own -- across the end
+// of the pass and of the call too: photon paths do not depend on hitpoints, so the batches of the NEXT passes are
+// traced ahead on the assumption that the caller will ask for the same photon range again (dropped if it does
+// not).  A tracer launch lasts as long as its longest photon path -- a few photons bounce thousands of times inside
+// the glass sphere, 10 ms and more against ~4 ms per pass -- so the look-ahead is several batches deep (NBUF - 1):
+// with two, every third pass waited for its tracer (profiles/r02_pass_gaps_*.txt).
 extern "C" int sppm_photon_pass(sppm_ctx* c, int32_t pass, int64_t first, int64_t count)
 {
     if (!c || pass < 0 || first < 0 || count < 0) return fail(SPPM_ERR_INVALID, "sppm_photon_pass: bad argument");
@@ -1467,67 +1548,53 @@ extern "C" int sppm_photon_pass(sppm_ctx* c, int32_t pass, int64_t first, int64_
         if (!c->order_valid) return fail(SPPM_ERR_STATE, "sppm_photon_pass: no eye pass has run on this context yet");
         if (!c->gs.valid) { rc = stats_read(c); if (rc) return rc; }
     }
-    int64_t n = std::min(batch_size(c, c->photons_applied), count);
-    int b;
-    if (c->pre.valid && c->pre.pass == pass && c->pre.first == first && c->pre.count == n) {
-        b = c->pre.buf;
-        c->pre = c->pre2; c->pre2.valid = 0;
-    } else {
-        rc = discard_prefetch(c);
-        if (rc) return rc;
-        b = c->cur;
-        rc = launch_ahead(c, b, pass, first, n);
-        if (rc) return rc;
+    if (c->pre.valid) {  // a batch started through sppm_look_ahead: the first of the queue, if nothing else is in it
+        if (c->ahead.empty()) { c->ahead.push_back(c->pre); c->pre.valid = 0; }
+        else { rc = discard_prefetch(c); if (rc) return rc; }
     }
-    const bool single = n == count;  // the whole call is one batch (the steady state of a long render)
-    for (int64_t done = 0; done < count;) {
-        // trace ahead into the other buffer
-        const int nb = (b + 1) % NBUF;
-        int64_t nn = 0; int npass = pass; int64_t nfirst = first + done + n;
-        bool next_call = false;  // the batch traced ahead belongs to the call expected after this one
-        if (done + n < count) nn = std::min(batch_size(c, c->photons_applied + (uint64_t)n), count - done - n);
-        else if (c->prefetch && c->algo == 1) {
-            // classic PPM has one run of photons, usually fed in several calls: the first batch of the next
-            // call, assumed to ask for as many photons as this one (dropped if it does not)
-            nfirst = first + count;
-            nn = std::max<int64_t>(0, std::min({batch_size(c, c->photons_applied + (uint64_t)n), count, c->cfg.photons_per_pass - nfirst}));
-            next_call = nn > 0;
-        } else if (c->prefetch) {
-            npass = pass + 1; nfirst = first; nn = std::min(batch_size(c, c->photons_applied + (uint64_t)n), count);
-            next_call = nn > 0;
-            rc = eye_prefetch(c, pass + 1);
+    const int depth = c->sampler == 1 ? 0 : c->ahead_depth;  // the sequential reference stream cannot run ahead
+    sppm_ctx::Pre cur;
+    cur.valid = 1; cur.buf = -1; cur.pass = pass; cur.first = first; cur.count = std::min(batch_size(c, c->photons_applied), count);
+    for (;;) {
+        // the current batch: traced ahead during an earlier batch or call, or traced now
+        if (!c->ahead.empty() && c->ahead.front().pass == cur.pass && c->ahead.front().first == cur.first && c->ahead.front().count == cur.count) {
+            cur.buf = c->ahead.front().buf;
+            c->ahead.pop_front();
+        } else {
+            rc = discard_prefetch(c);
+            if (rc) return rc;
+            cur.buf = c->cur;
+            rc = launch_ahead(c, cur.buf, cur.pass, cur.first, cur.count);
             if (rc) return rc;
         }
-        bool have = false;  // the batch wanted in buffer nb was traced during an earlier call
-        if (c->pre.valid) {
-            have = nn > 0 && c->pre.buf == nb && c->pre.pass == npass && c->pre.first == nfirst && c->pre.count == nn;
-            if (!have) { rc = discard_prefetch(c); if (rc) return rc; }
-        }
-        if (nn > 0 && !have) { rc = launch_ahead(c, nb, npass, nfirst, nn); if (rc) return rc; }
-        // Steady state (every call one batch of the same size): the batch after the next as well.  A tracer launch lasts as
-        // long as its longest photon path, often longer than a pass; started two calls ahead it is never waited for.
-        if (next_call && single && !c->pre2.valid) {
-            int p2 = npass; int64_t f2 = nfirst, n2 = nn;
-            if (c->algo == 1) { f2 = nfirst + nn; n2 = std::min(nn, c->cfg.photons_per_pass - f2); }
-            else p2 = npass + 1;
-            if (n2 > 0) {
-                const int nb2 = (b + 2) % NBUF;
-                rc = launch_ahead(c, nb2, p2, f2, n2);
+        // top the queue up with the batches expected next (ring buffers cur.buf + 1, + 2, ...)
+        {
+            sppm_ctx::Pre last = cur;
+            uint64_t applied = c->photons_applied + (uint64_t)cur.count;
+            for (const sppm_ctx::Pre& q : c->ahead) { last = q; applied += (uint64_t)q.count; }
+            while ((int)c->ahead.size() < depth) {
+                sppm_ctx::Pre nb;
+                if (!batch_after(c, first, count, last, applied, &nb)) break;
+                nb.buf = (cur.buf + 1 + (int)c->ahead.size()) % NBUF;
+                if (c->algo == 0 && nb.pass == pass + 1) { rc = eye_prefetch(c, pass + 1); if (rc) return rc; }
+                rc = launch_ahead(c, nb.buf, nb.pass, nb.first, nb.count);
                 if (rc) return rc;
-                c->pre2.valid = 1; c->pre2.buf = nb2; c->pre2.pass = p2; c->pre2.first = f2; c->pre2.count = n2;
+                c->ahead.push_back(nb);
+                last = nb; applied += (uint64_t)nb.count;
             }
         }
-        // gather batch b
-        HIPCHK(hipStreamWaitEvent(c->stream, c->ev_traced[b], 0));
-        set_cur(c, b);
-        c->rec_first = first + done; c->rec_end = first + done + n;
+        // gather the current batch
+        HIPCHK(hipStreamWaitEvent(c->stream, c->ev_traced[cur.buf], 0));
+        set_cur(c, cur.buf);
+        c->rec_first = cur.first; c->rec_end = cur.first + cur.count;
         rc = sppm_gather(c);
         if (rc) return rc;
-        HIPCHK(hipEventRecord(c->ev_free[b], c->stream));
-        done += n;
-        if (next_call) { c->pre.valid = 1; c->pre.buf = nb; c->pre.pass = npass; c->pre.first = nfirst; c->pre.count = nn; }
-        else if (have) { c->pre = c->pre2; c->pre2.valid = 0; }  // consumed within this call
-        b = nb; n = nn;
+        HIPCHK(hipEventRecord(c->ev_free[cur.buf], c->stream));
+        if (cur.first + cur.count >= first + count) break;
+        sppm_ctx::Pre nx;
+        const int64_t nf = cur.first + cur.count;
+        nx.valid = 1; nx.buf = -1; nx.pass = pass; nx.first = nf; nx.count = std::min(batch_size(c, c->photons_applied), first + count - nf);
+        cur = nx;
     }
     return SPPM_OK;
 }
@@ -1640,7 +1707,7 @@ extern "C" int sppm_check(sppm_ctx* c)
     if (!c) return fail(SPPM_ERR_INVALID, "sppm_check: null context");
     CTX_DEVICE(c, "sppm_check");
     int32_t err[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int b = 0; b < NBUF; b++) HIPCHK(hipStreamSynchronize(c->tstream[b]));
+    for (int b = 0; b < NTS; b++) HIPCHK(hipStreamSynchronize(c->tstream[b]));
     HIPCHK(hipMemcpyAsync(err, c->d_err, sizeof err, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     int rc = resolve_events(c);
@@ -1678,7 +1745,9 @@ extern "C" int sppm_download_hitpoints(sppm_ctx* c, int32_t* h_valid, int32_t* h
             for (int k = 0; k < 3; k++) { f[1 + k] = pos[k * P + i]; f[4 + k] = nrm[k * P + i]; f[7 + k] = w[k * P + i]; }
         }
     }
-    if (h_r2) HIPCHK(hipMemcpy(h_r2, c->hp.r2, P * 8, hipMemcpyDeviceToHost));
+    // radius, count and flux of a pixel that has no hitpoint (yet) are reported as zero: the eye pass of the NEXT pass,
+    // running ahead, may already have initialised them for a pixel that becomes valid then
+    if (h_r2) { HIPCHK(hipMemcpy(h_r2, c->hp.r2, P * 8, hipMemcpyDeviceToHost)); for (size_t i = 0; i < P; i++) if (!valid[i]) h_r2[i] = 0.0; }
     if (h_n) {
         if (c->cfg.update_rule == 0) HIPCHK(hipMemcpy(h_n, c->hp.n, P * 4, hipMemcpyDeviceToHost));
         else {
@@ -1686,6 +1755,7 @@ extern "C" int sppm_download_hitpoints(sppm_ctx* c, int32_t* h_valid, int32_t* h
             HIPCHK(hipMemcpy(nd.data(), c->hp.nd, P * 8, hipMemcpyDeviceToHost));
             for (size_t i = 0; i < P; i++) h_n[i] = (int32_t)nd[i];
         }
+        for (size_t i = 0; i < P; i++) if (!valid[i]) h_n[i] = 0;
     }
     auto soa3 = [&](const double* d, double* h) -> int {
         std::vector<double> t(3 * P);
@@ -1693,7 +1763,11 @@ extern "C" int sppm_download_hitpoints(sppm_ctx* c, int32_t* h_valid, int32_t* h
         for (size_t i = 0; i < P; i++) for (int k = 0; k < 3; k++) h[3 * i + k] = t[k * P + i];
         return 0;
     };
-    if (h_flux) { int rc = soa3(c->cfg.update_rule == 0 ? c->hp.flux : c->hp.tau, h_flux); if (rc) return rc; }
+    if (h_flux) {
+        int rc = soa3(c->cfg.update_rule == 0 ? c->hp.flux : c->hp.tau, h_flux);
+        if (rc) return rc;
+        for (size_t i = 0; i < P; i++) if (!valid[i]) h_flux[3 * i] = h_flux[3 * i + 1] = h_flux[3 * i + 2] = 0.0;
+    }
     if (h_ld) { int rc = soa3(c->hp.ld, h_ld); if (rc) return rc; }
     return SPPM_OK;
 }
@@ -1849,7 +1923,7 @@ extern "C" int sppm_counters(sppm_ctx* c, uint64_t h_out[16])
 {
     if (!c || !h_out) return fail(SPPM_ERR_INVALID, "sppm_counters: null argument");
     unsigned long long d[8], qmax = 0;
-    for (int b = 0; b < NBUF; b++) HIPCHK(hipStreamSynchronize(c->tstream[b]));
+    for (int b = 0; b < NTS; b++) HIPCHK(hipStreamSynchronize(c->tstream[b]));
     HIPCHK(hipMemcpyAsync(d, c->d_counters, sizeof d, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(&qmax, c->d_qmax, sizeof qmax, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));

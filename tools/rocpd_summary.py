@@ -60,8 +60,38 @@ def pmc(fetch_db, write_db, w, h, m, steps):
     print(json.dumps({"gather_bytes_per_launch": out["gather_bytes_per_launch"], "launches": g["launches"]}))
 
 
+def sq(out_json, dbs):
+    """per kernel: launches and the per-launch average of every counter found in the given --pmc databases"""
+    out = {}
+    for path in dbs:
+        db = sqlite3.connect(path)
+        tot, calls = collections.defaultdict(float), collections.defaultdict(set)
+        for name, counter, val, disp in db.execute("select kernel_name, counter_name, value, dispatch_id from counters_collection"):
+            k = short(name)
+            if len(k) > 120:
+                continue
+            tot[(k, counter)] += val
+            calls[(k, counter)].add(disp)
+        for (k, counter), v in tot.items():
+            n = max(1, len(calls[(k, counter)]))
+            out.setdefault(k, {"launches": n})[counter] = v / n
+    for k, d in out.items():   # derived figures the guide names
+        if "FETCH_SIZE" in d or "WRITE_SIZE" in d:
+            d["hbm_bytes_per_launch"] = 2 * 1024 * d.get("FETCH_SIZE", 0.0) + 1024 * d.get("WRITE_SIZE", 0.0)
+        if d.get("SQ_BUSY_CYCLES") and d.get("SQ_ACTIVE_INST_VALU"):
+            d["valu_busy_share_of_sq_busy_cycles"] = d["SQ_ACTIVE_INST_VALU"] / d["SQ_BUSY_CYCLES"]
+    keep = {k: v for k, v in sorted(out.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", 0.0))}
+    json.dump({"method": "rocprofv3 --pmc, one run per group of counters (tools/pmc_passes.sh); values are per-launch averages summed over "
+                         "all XCDs / shader engines; FETCH_SIZE and WRITE_SIZE in KiB, hbm_bytes_per_launch = 2 x FETCH_SIZE (gfx950) + WRITE_SIZE in bytes",
+               "kernels": keep}, open(out_json, "w"), indent=1)
+    for k in list(keep)[:6]:
+        print(k, json.dumps(keep[k]))
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3])
+    elif sys.argv[1] == "sq":
+        sq(sys.argv[2], sys.argv[3:])
     else:
         pmc(sys.argv[2], sys.argv[3], *[int(x) for x in sys.argv[4:8]])

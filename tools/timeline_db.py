@@ -10,7 +10,7 @@ db = sqlite3.connect(sys.argv[1])
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 floor_us = float(sys.argv[3]) if len(sys.argv) > 3 else 10.0
 rows = list(db.execute("select name, start, end, stream_id, queue_id from kernels order by start"))
-g = [i for i, r in enumerate(rows) if "k_gather_tiles" in r[0]]
+g = [i for i, r in enumerate(rows) if "k_gather_tiles" in r[0] or "k_deposit_tiles" in r[0]]
 a, b = g[-1 - k], g[-k]
 t0 = rows[a][1]
 print("gather to gather: %.1f us" % ((rows[b][1] - rows[a][1]) / 1e3))
