@@ -1576,13 +1576,14 @@ extern "C" int sppm_photon_pass(sppm_ctx* c, int32_t pass, int64_t first, int64_
                 sppm_ctx::Pre nb;
                 if (!batch_after(c, first, count, last, applied, &nb)) break;
                 nb.buf = (cur.buf + 1 + (int)c->ahead.size()) % NBUF;
-                if (c->algo == 0 && nb.pass == pass + 1) { rc = eye_prefetch(c, pass + 1); if (rc) return rc; }
                 rc = launch_ahead(c, nb.buf, nb.pass, nb.first, nb.count);
                 if (rc) return rc;
                 c->ahead.push_back(nb);
                 last = nb; applied += (uint64_t)nb.count;
             }
         }
+        // the caller is expected to go on with the next pass: its eye pass runs ahead too (eye paths do not depend on photons)
+        if (c->algo == 0 && !c->ahead.empty() && c->ahead.front().pass == pass + 1) { rc = eye_prefetch(c, pass + 1); if (rc) return rc; }
         // gather the current batch
         HIPCHK(hipStreamWaitEvent(c->stream, c->ev_traced[cur.buf], 0));
         set_cur(c, cur.buf);
