@@ -115,12 +115,14 @@ __device__ __forceinline__ DepRegion dep_region(const DepTile& t, const bool (&i
     return R;
 }
 
-// One wavefront per tile: the clusters, the records in each cluster's region (8 lookups in the summed-area
-// table), and the cut of every region's records into at most DEP_MAX_CHUNKS chunks of ~chunk_records.  Tile k
+// One wavefront per tile: the clusters, the records in each cluster's region, and the cut of every region's records into at most DEP_MAX_CHUNKS chunks of ~chunk_records.  Tile k
 // writes its pieces to raw[k*64 ..] as (cost estimate << 32 | item) and their number (<= 64) to n_pieces[k].
-__global__ void __launch_bounds__(256) k_deposit_plan(HpArrays hp, const uint32_t* __restrict__ sat, TileParams tp, int n_tiles, uint32_t chunk_records,
-                                                      unsigned long long* __restrict__ raw, uint8_t* __restrict__ n_pieces, uint32_t* __restrict__ est)
+__global__ void __launch_bounds__(256) k_deposit_plan(HpArrays hp, const uint32_t* __restrict__ cell_start, TileParams tp, int n_tiles, uint32_t chunk_records,
+                                                      unsigned long long* __restrict__ raw, uint8_t* __restrict__ n_pieces, uint32_t* __restrict__ est,
+                                                      unsigned int* __restrict__ q)
 {
+    // (the item queue of the batch before is done with: cleared here, ahead of the kernels that count into it)
+    if (blockIdx.x == 0 && threadIdx.x < 2 + ITEM_CLASSES) q[threadIdx.x] = 0u;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int k = blockIdx.x * 4 + wv;
     if (k >= n_tiles) return;
@@ -135,8 +137,23 @@ __global__ void __launch_bounds__(256) k_deposit_plan(HpArrays hp, const uint32_
         bool inc[DEP_H];
         dep_next_cluster(remaining, c, t, lane, tp.cluster_d, inc);
         const DepRegion R = dep_region(t, inc, tp);
-        const unsigned int T = sat_box(sat, tp.g.nx, tp.g.ny, R.cx0, R.cx1, R.cy0, R.cy1, R.cz0, R.cz1, lane);
-        const unsigned int cells = (unsigned int)((R.cx1 - R.cx0 + 1) * (R.cy1 - R.cy0 + 1) * (R.cz1 - R.cz0 + 1));
+        // the records in the region's cells, counted directly (one slab: a cell's count is a difference of two starts;
+        // a few hundred cells, 64 per trip -- cheaper than building a summed-area table over all cells for 8 lookups)
+        const int kx = R.cx1 - R.cx0 + 1, ky = R.cy1 - R.cy0 + 1, kz = R.cz1 - R.cz0 + 1;
+        const unsigned int cells = (unsigned int)(kx * ky * kz);
+        unsigned int T = 0;
+        for (int qbase = 0; qbase < (int)cells; qbase += 64) {
+            const int qi = qbase + lane;
+            uint32_t cnt = 0;
+            if (qi < (int)cells) {
+                const int ix = R.cx0 + qi % kx, iy = R.cy0 + (qi / kx) % ky, iz = R.cz0 + qi / (kx * ky);
+                const uint32_t b = (uint32_t)((iz * tp.g.ny + iy) * tp.g.nx + ix);
+                cnt = cell_start[b + 1] - cell_start[b];
+            }
+            T += cnt;
+        }
+        for (int off = 32; off > 0; off >>= 1) T += __shfl_xor(T, off);
+        T = (unsigned int)__builtin_amdgcn_readfirstlane((int)T);
         // every later cluster (at most DEP_MAX_CLUSTERS - 1 - c of them) keeps one of the tile's 64 slots
         const int avail = 64 - n_out - (DEP_MAX_CLUSTERS - 1 - c);
         int cn = (int)((T + chunk_records - 1) / chunk_records);

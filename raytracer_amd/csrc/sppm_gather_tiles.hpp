@@ -213,6 +213,18 @@ __global__ void __launch_bounds__(1024) k_tile_hist(const uint8_t* __restrict__ 
     if (threadIdx.x == 0) { st->live_tiles = live; st->est_sum = esum; }
 }
 
+// what the host reads one batch late, written straight into its pinned slot (one launch instead of three copies)
+struct StatSnapshot { TileStats hs; unsigned long long bbq[6]; unsigned long long cnt[24]; };
+__global__ void k_stat_snapshot(const TileStats* __restrict__ st, const unsigned long long* __restrict__ bb, const unsigned long long* __restrict__ counters,
+                                StatSnapshot* __restrict__ out)
+{
+    const int t = threadIdx.x;
+    if (t < 64) out->hs.hist[t] = st->hist[t];
+    if (t == 0) { out->hs.live_tiles = st->live_tiles; out->hs.pad = 0; out->hs.est_sum = st->est_sum; }
+    if (t < 6) out->bbq[t] = bb[t];
+    if (t < 24) out->cnt[t] = counters[t];
+}
+
 // records per cell summed over the slabs of the batch (what the plan's estimates read)
 __global__ void k_cell_totals(const uint32_t* __restrict__ cell_start, int ncells, int S, uint32_t* __restrict__ cell_tot)
 {
@@ -345,9 +357,12 @@ __global__ void __launch_bounds__(256) k_items_hist(const unsigned long long* __
     __syncthreads();
     if (threadIdx.x < ITEM_CLASSES && h[threadIdx.x]) { atomicAdd(&q[2 + threadIdx.x], h[threadIdx.x]); atomicAdd(&q[0], h[threadIdx.x]); }
 }
-__global__ void k_items_bases(unsigned int* __restrict__ q)
+// (also clears the record counter of the batch's buffer: its records are binned by now, and a one-word memset queued
+// behind the gather would be one more launch between two gathers)
+__global__ void k_items_bases(unsigned int* __restrict__ q, unsigned long long* __restrict__ rec_count)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    *rec_count = 0ull;
     unsigned int run = 0;
     for (int c = ITEM_CLASSES - 1; c >= 0; c--) { const unsigned int n = q[2 + c]; q[2 + c] = run; run += n; }
     q[1] = 0;

@@ -142,8 +142,9 @@ struct sppm_ctx {
     struct BinSet { RecArrays rec_s; uint32_t *rec_bucket, *cell_cnt, *cell_start, *cursor, *block_sum, *total; TileGrid g; int binned; } bins[NBUF];
     // Tile statistics travel to the host one batch late (pinned slots, no stream sync in steady state):
     // they only size the grid and balance the load, never change a result.
-    struct StatSlot { TileStats hs; unsigned long long bbq[6]; unsigned long long cnt[24]; };
-    StatSlot* h_stat; hipEvent_t ev_stat[2]; int stat_w; long stat_n;
+    typedef StatSnapshot StatSlot;
+    StatSlot* h_stat; StatSlot* d_stat_map;  // pinned host memory and the address the device writes it through
+    hipEvent_t ev_stat[2]; int stat_w; long stat_n;
     struct { double lo[3], cell, cluster_d; int64_t dims[3], ncells; int valid; } gs;  // spatial part of the grid, from the last statistics read
     unsigned long long snap_prev[24]; int snap_prev_valid; long gather_j; int64_t hist_S[4], hist_B[4];
     uint32_t n_buckets;
@@ -491,7 +492,9 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
         sppm_destroy(c); return fail(SPPM_ERR_HIP, "pinned memory / event for the packed rows");
     }
     c->h_stat = nullptr; c->ev_stat[0] = c->ev_stat[1] = nullptr; c->stat_w = 0; c->stat_n = 0; c->gs.valid = 0; c->snap_prev_valid = 0; c->gather_j = 0;
-    if (hipHostMalloc((void**)&c->h_stat, 2 * sizeof(sppm_ctx::StatSlot), hipHostMallocDefault) != hipSuccess) { sppm_destroy(c); return fail(SPPM_ERR_HIP, "pinned host memory for the tile statistics"); }
+    c->d_stat_map = nullptr;
+    if (hipHostMalloc((void**)&c->h_stat, 2 * sizeof(sppm_ctx::StatSlot), hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&c->d_stat_map, c->h_stat, 0) != hipSuccess) { sppm_destroy(c); return fail(SPPM_ERR_HIP, "pinned host memory for the tile statistics"); }
     for (int b = 0; b < 2; b++)
         if (hipEventCreateWithFlags(&c->ev_stat[b], hipEventDisableTiming) != hipSuccess) { sppm_destroy(c); return fail(SPPM_ERR_HIP, "creating events failed"); }
     TRY(dev_alloc(c, &c->d_counters, 24)); TRY(dev_alloc(c, &c->d_r2max, 1)); TRY(dev_alloc(c, &c->d_qmax, 1)); TRY(dev_alloc(c, &c->d_eye_next, 1));
@@ -1159,10 +1162,8 @@ static int stats_launch(sppm_ctx* c)
         hipLaunchKernelGGL(k_tile_hist, dim3(1), dim3(1024), 0, st, c->d_ext_bin, c->est_valid ? c->d_est : (const uint32_t*)nullptr, c->n_owned, c->d_stats);
         HIPCHK(hipGetLastError());
     }
-    sppm_ctx::StatSlot* slot = c->h_stat + c->stat_w;
-    HIPCHK(hipMemcpyAsync(&slot->hs, c->d_stats, sizeof slot->hs, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(slot->bbq, c->d_hp_bb, sizeof slot->bbq, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(slot->cnt, c->d_counters, sizeof slot->cnt, hipMemcpyDeviceToHost, st));
+    hipLaunchKernelGGL(k_stat_snapshot, dim3(1), dim3(64), 0, st, c->d_stats, c->d_hp_bb, c->d_counters, c->d_stat_map + c->stat_w);
+    HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev_stat[c->stat_w], st));
     c->stat_w ^= 1; c->stat_n++;
     return 0;
@@ -1306,7 +1307,7 @@ static int gather_tiles(sppm_ctx* c)
     hipLaunchKernelGGL(k_sat_axis, dim3(nblk(g.nx * g.ny, 64)), dim3(64), 0, st, c->d_cell_tot, g.nx, g.ny, g.nz, 2);
     hipLaunchKernelGGL(k_tile_plan, dim3(nblk(c->n_owned, 4)), dim3(256), 0, st, c->hp, c->d_cell_tot, tp, split_thr, c->d_items_raw, c->d_n_pieces, c->d_est);
     hipLaunchKernelGGL(k_items_hist, dim3(nblk(c->n_owned, 256)), dim3(256), 0, st, c->d_items_raw, c->d_n_pieces, c->n_owned, c->d_item_q);
-    hipLaunchKernelGGL(k_items_bases, dim3(1), dim3(64), 0, st, c->d_item_q);
+    hipLaunchKernelGGL(k_items_bases, dim3(1), dim3(64), 0, st, c->d_item_q, c->d_rec_count);
     hipLaunchKernelGGL(k_items_scatter, dim3(nblk(c->n_owned, 256)), dim3(256), 0, st, c->d_items_raw, c->d_n_pieces, c->n_owned, c->d_item_q, c->d_items);
     c->est_valid = 1; c->est_range = range;
     // persistent wavefronts: 4 per SIMD on every CU (fewer if there are few tiles)
@@ -1344,7 +1345,7 @@ static int gather_tiles(sppm_ctx* c)
     c->gather_batches++;
     c->photons_applied += (uint64_t)range;
     c->rec_first = c->rec_end = 0;
-    HIPCHK(hipMemsetAsync(c->d_rec_count, 0, sizeof(unsigned long long), st));
+    // (the buffer's record counter was cleared by k_items_bases)
     if (!dbg) return SPPM_OK;
     unsigned long long cnt1[24];
     HIPCHK(hipMemcpyAsync(cnt1, c->d_counters, sizeof cnt1, hipMemcpyDeviceToHost, st));
@@ -1410,15 +1411,10 @@ static int deposit_tiles(sppm_ctx* c)
     tp.g = g;
     tp.cluster_d = c->gs.cluster_d;
     c->gather_j++;
-    HIPCHK(hipMemsetAsync(c->d_item_q, 0, sizeof(unsigned int) * (2 + ITEM_CLASSES), st));
-    hipLaunchKernelGGL(k_cell_totals, dim3(nblk(g.ncells, 256)), dim3(256), 0, st, BS.cell_start, g.ncells, g.S, c->d_cell_tot);
-    hipLaunchKernelGGL(k_sat_axis, dim3(nblk(g.ny * g.nz, 64)), dim3(64), 0, st, c->d_cell_tot, g.nx, g.ny, g.nz, 0);
-    hipLaunchKernelGGL(k_sat_axis, dim3(nblk(g.nx * g.nz, 64)), dim3(64), 0, st, c->d_cell_tot, g.nx, g.ny, g.nz, 1);
-    hipLaunchKernelGGL(k_sat_axis, dim3(nblk(g.nx * g.ny, 64)), dim3(64), 0, st, c->d_cell_tot, g.nx, g.ny, g.nz, 2);
     const int n_dep_tiles = (c->n_own_pix + DEP_TILE - 1) / DEP_TILE;  // DEP_H hitpoints per lane
-    hipLaunchKernelGGL(k_deposit_plan, dim3(nblk(n_dep_tiles, 4)), dim3(256), 0, st, c->hp, c->d_cell_tot, tp, n_dep_tiles, (uint32_t)c->dep_chunk, c->d_items_raw, c->d_n_pieces, c->d_est);
+    hipLaunchKernelGGL(k_deposit_plan, dim3(nblk(n_dep_tiles, 4)), dim3(256), 0, st, c->hp, BS.cell_start, tp, n_dep_tiles, (uint32_t)c->dep_chunk, c->d_items_raw, c->d_n_pieces, c->d_est, c->d_item_q);
     hipLaunchKernelGGL(k_items_hist, dim3(nblk(n_dep_tiles, 256)), dim3(256), 0, st, c->d_items_raw, c->d_n_pieces, n_dep_tiles, c->d_item_q);
-    hipLaunchKernelGGL(k_items_bases, dim3(1), dim3(64), 0, st, c->d_item_q);
+    hipLaunchKernelGGL(k_items_bases, dim3(1), dim3(64), 0, st, c->d_item_q, c->d_rec_count);
     hipLaunchKernelGGL(k_items_scatter, dim3(nblk(n_dep_tiles, 256)), dim3(256), 0, st, c->d_items_raw, c->d_n_pieces, n_dep_tiles, c->d_item_q, c->d_items);
     c->est_valid = 0;  // (the estimates of the ordered gather's plan are not made here)
     const int blocks = std::max(1, std::min(nblk(n_dep_tiles, 4) * 4, (int)env_i64("SPPM_DEP_BLOCKS", 256 * (DEP_H == 1 ? 4 : 3))));
@@ -1444,7 +1440,7 @@ static int deposit_tiles(sppm_ctx* c)
     c->gather_batches++;
     c->photons_applied += (uint64_t)range;
     c->rec_first = c->rec_end = 0;
-    HIPCHK(hipMemsetAsync(c->d_rec_count, 0, sizeof(unsigned long long), st));
+    // (the buffer's record counter was cleared by k_items_bases)
     return SPPM_OK;
 }
 
