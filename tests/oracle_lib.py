@@ -60,6 +60,9 @@ def lib():
     L.orc_get_deposits.argtypes = [C.c_void_p, C.c_void_p]
     L.orc_fixed_scale.restype = C.c_double
     L.orc_fixed_scale.argtypes = [C.c_void_p]
+    L.orc_photon_pass_mt.restype = C.c_int
+    L.orc_photon_pass_mt.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_int, C.POINTER(C.c_double)]
+    L.orc_max_threads.restype = C.c_int
     L.orc_mt_samples.argtypes = [C.c_uint32, C.c_int, C.c_void_p]
     L.orc_xorshift.argtypes = [C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]
     L.orc_xs_stream.argtypes = [C.c_uint32, C.c_uint64, C.c_int, C.c_void_p]
@@ -164,6 +167,13 @@ class Oracle:
         out["acc_rec"] = out["acc_rec"][:t.acc_n]
         out["acc_pix"] = out["acc_pix"][:t.acc_n]
         return out
+
+    def photon_pass_mt(self, i, count, first=0, threads=None):
+        """the same pass on `threads` host cores (OpenMP; default: all the runtime offers); returns the seconds spent"""
+        sec = C.c_double()
+        rc = self.L.orc_photon_pass_mt(self.h, i, first, count, threads or self.L.orc_max_threads(), C.byref(sec))
+        assert rc == 0
+        return sec.value
 
     def end_pass(self):
         self.L.orc_end_pass(self.h)

@@ -127,3 +127,50 @@ def test_classic_ppm(golden, tag):
     # creation-order sums (what the GPU path does) differ only by the rounding of a few-term sum
     img1 = o.resolve(photons, order=1)
     assert np.abs(img1 - img).max() <= 4e-16 * np.abs(img).max()
+
+
+@pytest.mark.parametrize("rule", [0, 1])
+def test_all_core_photon_pass_equals_serial(rule):
+    """orc_photon_pass_mt (bench.py's all-core CPU baseline) against the serial pass: identical state and image for
+    3 threads, for the per-photon rule (hitpoints cut into one kd-tree per thread, every thread replays all photon
+    hits in order) and the per-pass rule (atomic integer deposits)."""
+    import oracle_lib as ol
+    from raytracer_amd.scene import CORNELL_SPHERES
+    W, H, M = 48, 36, 6000
+    outs = []
+    for mt in (False, True):
+        o = ol.Oracle(ol.make_params(W, H, sampler=1, math=1, photons_per_pass=M, rule=rule), ol.make_spheres(CORNELL_SPHERES))
+        for i in range(2):
+            o.eye_pass(i)
+            if mt:
+                o.photon_pass_mt(i, M // 2, first=0, threads=3)
+                o.photon_pass_mt(i, M - M // 2, first=M // 2, threads=3)
+            else:
+                o.photon_pass(i, M)
+            o.end_pass()
+        outs.append((o.state(), o.resolve(1, M), o.counters()))
+        o.close()
+    (s0, img0, c0), (s1, img1, c1) = outs
+    for k in ("valid", "n", "r2", "flux"):
+        assert np.array_equal(np.ascontiguousarray(s0[k]).view(np.uint8), np.ascontiguousarray(s1[k]).view(np.uint8)), k
+    assert np.array_equal(img0.view(np.uint64), img1.view(np.uint64))
+    assert c0["updates"] == c1["updates"] and c0["rays"] == c1["rays"]
+
+
+def test_all_core_classic_ppm_equals_serial():
+    import oracle_lib as ol
+    from raytracer_amd.scene import CORNELL_SPHERES
+    W, H, M = 48, 36, 6000
+    outs = []
+    for mt in (False, True):
+        o = ol.PpmOracle(ol.make_params(W, H, sampler=1, math=1, photons_per_pass=M, gather_radius2=5.0, initial_radius2=5.0), ol.make_spheres(CORNELL_SPHERES))
+        o.eye_pass()
+        if mt:
+            o.photon_pass_mt(0, M, threads=4)
+        else:
+            o.photon_pass(0, M)
+        outs.append((o.state(), o.counters()))
+        o.close()
+    for k in ("n", "r2", "flux"):
+        assert np.array_equal(np.ascontiguousarray(outs[0][0][k]).view(np.uint8), np.ascontiguousarray(outs[1][0][k]).view(np.uint8)), k
+    assert outs[0][1]["updates"] == outs[1][1]["updates"]
