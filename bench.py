@@ -29,30 +29,46 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
-def cpu_baseline(width, height, photons, seconds_target=12.0, table=None):
-    """The oracle (a faithful single-thread port of the reference's kd-tree SPPM) on this box's host
-    cores: eye pass 0 + kd build + a bounded number of photons of pass 0, same workload geometry."""
+def cpu_baseline(width, height, photons, rule, seconds_target=12.0, table=None):
+    """The oracle (a port of the reference's kd-tree SPPM; the reference itself is single-threaded) on this
+    box's host cores, same workload geometry and update rule: eye pass 0 + kd build (untimed), then a bounded number
+    of photons of pass 0 on ALL cores the OpenMP runtime offers (orc_photon_pass_mt: per-pass rule = photons shared
+    out, atomic integer deposits; per-photon rule = hitpoints cut into one kd-tree per thread, every thread replays
+    all photon hits in order -- both identical to the serial pass, tests/test_oracle_vs_reference.py), and on one."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as ol
     from raytracer_amd.scene import CORNELL_SPHERES
-    par = ol.make_params(width, height, sampler=1, math=1, photons_per_pass=photons)
-    orc = ol.Oracle(par, ol.make_spheres(table if table is not None else CORNELL_SPHERES))
-    t0 = time.perf_counter()
-    orc.eye_pass(0)
-    t_eye = time.perf_counter() - t0
-    n, done, t_ph = 2000 if table is None else 100, 0, 0.0
-    while t_ph < seconds_target and done < photons:
-        n = min(n, photons - done)
+    spheres = ol.make_spheres(table if table is not None else CORNELL_SPHERES)
+    cores = int(ol.lib().orc_max_threads())
+
+    def sample(threads, budget):
+        par = ol.make_params(width, height, sampler=1, math=1, photons_per_pass=photons, rule=rule)
+        orc = ol.Oracle(par, spheres)
         t0 = time.perf_counter()
-        orc.photon_pass(0, n, first=done)
-        t_ph += time.perf_counter() - t0
-        done += n
-        n *= 2
-    upd = orc.counters()["updates"]
-    orc.close()
-    return {"value": done / t_ph, "unit": "photons/s", "cores": 1, "kind": "port",
-            "sample": f"{width}x{height} pass 0: eye pass + kd-tree build {t_eye:.1f} s (not in value), then the first "
-                      f"{done} photons in {t_ph:.1f} s, {upd} hitpoint updates ({upd / t_ph:.3g} updates/s)"}
+        orc.eye_pass(0)
+        t_eye = time.perf_counter() - t0
+        n, done, t_ph = (2000 if table is None else 100) * threads, 0, 0.0
+        while t_ph < budget and done < photons:
+            n = min(n, photons - done)
+            if threads > 1:
+                t_ph += orc.photon_pass_mt(0, n, first=done, threads=threads)
+            else:
+                t0 = time.perf_counter()
+                orc.photon_pass(0, n, first=done)
+                t_ph += time.perf_counter() - t0
+            done += n
+            n *= 2
+        upd = orc.counters()["updates"]
+        orc.close()
+        return done, t_ph, upd, t_eye
+    done, t_ph, upd, t_eye = sample(cores, seconds_target)
+    out = {"value": done / t_ph, "unit": "photons/s", "cores": cores, "kind": "port",
+           "sample": f"{width}x{height} pass 0, {'per-pass' if rule == 1 else 'per-photon'} rule: eye pass + kd-tree build {t_eye:.1f} s (one core, not in value), "
+                     f"then the first {done} photons on {cores} cores (OpenMP) in {t_ph:.1f} s, {upd} hitpoint updates ({upd / t_ph:.3g} updates/s)"}
+    if cores > 1:
+        d1, t1, u1, _ = sample(1, seconds_target / 2)
+        out["one_core"] = {"value": d1 / t1, "unit": "photons/s", "sample": f"the first {d1} photons of the same pass on one core in {t1:.1f} s ({u1 / t1:.3g} updates/s)"}
+    return out
 
 
 def reference_check(photons=20000):
@@ -209,19 +225,142 @@ def measured_stream_bandwidth(torch, gib=2):
     return 2.0 * n * 8 * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
-def measured_traffic(width, height, photons, steps):
-    """HBM bytes per k_gather_tiles launch from the committed PMC passes (profiles/r01_pmc_traffic.json:
-    FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3 --pmc runs of this script, FETCH_SIZE
-    doubled as MI355X_MICROARCH.md prescribes for gfx950).  Counters cannot be read from inside a
-    normal run, so the figure is only reported for the workload it was measured on; otherwise null."""
+def measured_fma_peak(torch):
+    """FP64 vector FMA rate this box sustains (TFLOP/s), beside the 78.6 of the data sheet."""
+    import ctypes as C
+    from raytracer_amd import capi
+    v = C.c_double()
+    capi.check(capi.lib().sppm_measure_fma_peak(C.c_void_p(torch.cuda.current_stream().cuda_stream), C.byref(v)))
+    return v.value
+
+
+def measured_counters(width, height, photons, rule, steps):
+    """Per-launch hardware counters of the gather kernel from the committed rocprofv3 --pmc passes of this script
+    (profiles/r02_pmc_rule<R>.json, made by tools/pmc_passes.sh + tools/rocpd_summary.py sq: HBM bytes = 2 x FETCH_SIZE
+    (gfx950) + WRITE_SIZE, SQ busy / VALU / LDS cycles).  Counters cannot be read from inside a normal run; a file
+    matches by (width, height, photons per pass, rule) -- it says which passes it was averaged over."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", f"r02_pmc_rule{rule}.json")) as f:
             t = json.load(f)
-    except OSError:
+    except (OSError, ValueError):
         return None
-    if [width, height, photons, steps] != [t["width"], t["height"], t["photons"], t["steps"]]:
+    if [width, height, photons, rule] != [t.get("width"), t.get("height"), t.get("photons"), t.get("rule")]:
         return None
-    return t["gather_bytes_per_launch"]
+    return t
+
+
+# algorithmic work of the gather kernels (DESIGN.md section 5)
+PAIR_FLOP = 23.0      # FP64 operations of one (record, hitpoint) test: 3 sub, 5 |d|^2, 5 n.g, 5 g.d, 5 flatness with its band
+UPDATE_FLOP = {0: 24.0, 1: 0.0}   # per accepted update: rule 0 = shrink factor, 3 x (w c f / pi), (acc + add) g; rule 1 = integer adds only
+FP64_PEAK = 78.6      # TFLOP/s, vector FP64 with every operation an FMA (MI355X data sheet); 39.3 T operations/s without FMA
+
+
+def run_render(args, rank, world, barrier, rule, table, torch, dist):
+    """one timed render with the given update rule; returns the measurements of this rank plus the image"""
+    from raytracer_amd.parallel import ShardedSppm, all_reduce_sum
+    W, H, M = args.width, args.height, args.photons
+    if args.warmup > 0:  # untimed: a scratch render of W passes
+        scratch = ShardedSppm(W, H, photons_per_rank=M, rank=rank, world=world, spheres=table, rule=rule)
+        scratch.total_passes = args.warmup
+        for i in range(args.warmup):
+            scratch.step(i)
+        scratch.ctx.check()
+        scratch.close()
+    job = ShardedSppm(W, H, photons_per_rank=M, rank=rank, world=world, spheres=table, rule=rule)
+    job.total_passes = args.steps
+    job.time_stages = world > 1
+    job.ctx.set_timing(True)
+    c0 = job.ctx.counters()
+    barrier()
+    t0 = time.perf_counter()
+    progress = os.environ.get("SPPM_BENCH_PROGRESS")
+    for i in range(args.steps):
+        job.step(i)
+        if progress and rank == 0:
+            torch.cuda.synchronize()
+            print(f"[bench] pass {i} done at {time.perf_counter() - t0:.3f} s", file=sys.stderr, flush=True)
+    img = job.gather_image() if world > 1 else job.image   # the final image on every rank
+    job.ctx.check()   # drains the look-ahead streams too
+    barrier()
+    dt = time.perf_counter() - t0
+    c1 = job.ctx.counters()
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    # per-rank counter deltas summed over ranks
+    d = torch.tensor([c1[k] - c0[k] for k in ("rays", "records", "candidates", "updates")], dtype=torch.float64, device="cuda")
+    if world > 1:
+        h = tmax.cpu() if dist.get_backend() == "gloo" else tmax
+        dist.all_reduce(h, op=dist.ReduceOp.MAX)
+        tmax = h
+        all_reduce_sum(d)
+    out = {"dt": float(tmax.item()), "c0": c0, "c1": c1, "sums": [float(x) for x in d.tolist()], "image": img, "describe": job.describe(),
+           "replicated_trace": job.replicated_trace, "exchanged_bytes": job.exchanged_bytes,
+           "exchange_ms": [a.elapsed_time(b) for _, a, b in job.stage_events]}
+    job.close()
+    return out
+
+
+def report(args, world, rule, r, table_name):
+    """the JSON fields of one render"""
+    W, H, M = args.width, args.height, args.photons
+    c0, c1 = r["c0"], r["c1"]
+    dt = r["dt"]
+    rays, records, cand, upd = r["sums"]
+    photons_total = float(M) * world * args.steps
+    g_ns = c1["gather_ns"] - c0["gather_ns"]
+    g_launch = max(1, c1["gather_launches"] - c0["gather_launches"])
+    cand0, upd0 = c1["candidates"] - c0["candidates"], c1["updates"] - c0["updates"]
+    kernel = "k_gather_tiles" if rule == 0 else "k_deposit_tiles"
+    flop = PAIR_FLOP * cand0 + UPDATE_FLOP[rule] * upd0
+    tflops = flop / max(g_ns, 1) / 1e3 if g_ns else 0.0   # flop/ns = GFLOP/s
+    alg_bytes = 28.0 * cand0 + 32.0 * upd0                  # SURVEY 8(d): 28 B per pair examined + 32 B per accepted update
+    pm = measured_counters(W, H, M, rule, args.steps) if world == 1 else None
+    rule_name = "per-pass update (src/stochastic_ppm.h:721-741), deposits in 64-bit fixed point" if rule == 1 else "per-photon update (src/sppm2.h:391-421)"
+    out = {
+        "value": photons_total / dt, "ms_per_step": 1e3 * dt / args.steps,
+        "config": {"workload": f"{table_name} SPPM {W}x{H}, {M} photons/pass/GPU, passes 0..{args.steps - 1} of a fresh render, alpha 0.7, "
+                               f"initial r^2 25, search r^2 25, {rule_name}, XorShift streams",
+                   "update_rule": rule, "photons_per_pass": M * world, "width": W, "height": H, "parallelism": r["describe"]},
+        "hitpoint_updates_per_s": upd / dt, "rays_per_s": rays / dt,
+        "records_per_photon": records / max(1.0, float(M) * args.steps * (world if r["replicated_trace"] else 1)),
+        "updates_per_photon": upd / photons_total,
+        "roofline": {
+            "bound": "valu", "kernel": kernel, "achieved": tflops, "peak": FP64_PEAK, "unit": "TFLOP/s", "frac": tflops / FP64_PEAK,
+            "traffic": pm["hbm_bytes_per_launch"] if pm else None,
+            "launches": int(g_launch), "avg_launch_ms": g_ns / 1e6 / g_launch,
+            "flop_per_launch": flop / g_launch, "pairs_tested_per_launch": cand0 / g_launch, "updates_per_launch": upd0 / g_launch,
+            "tests_per_update": cand0 / max(1.0, float(upd0)),
+            # the byte accounting of SURVEY 8(d), kept beside the bound that the counters show
+            "alg_bytes_per_launch": alg_bytes / g_launch, "alg_GBps": alg_bytes / max(g_ns, 1),
+            "update_bytes_GBps_at_60B": 60.0 * upd0 / max(g_ns, 1), "update_bytes_frac_of_hbm_peak": 60.0 * upd0 / max(g_ns, 1) / 8000.0,
+            "note": "rank 0; bound = VALU issue: the committed SQ counters (profiles/r02_pmc_rule%d.json) show the kernel's SIMDs issuing vector "
+                    "instructions %s of the time with HBM at a few percent of 8 TB/s, so the roofline is the FP64 vector peak; achieved = 23 flop x "
+                    "(record, hitpoint) pairs tested%s / kernel time from HIP events on the kernel's stream; peak 78.6 TFLOP/s counts every operation as an "
+                    "FMA -- the tests run with contraction off (bit-exact parity), where the attainable rate is 39.3 T operations/s; traffic = HBM bytes per "
+                    "launch from rocprofv3 --pmc (2 x FETCH_SIZE + WRITE_SIZE) of %s" % (
+                        rule, ("%.0f %%" % (100.0 * pm["valu_active_share"])) if pm and pm.get("valu_active_share") else "most",
+                        " + 24 flop x accepted updates" if rule == 0 else "", pm.get("run", "the committed run") if pm else "(no committed counters for this workload)"),
+        },
+    }
+    if pm:
+        out["roofline"]["traffic_GBps"] = pm["hbm_bytes_per_launch"] / (pm.get("avg_launch_ms", g_ns / 1e6 / g_launch) * 1e6)
+        out["roofline"]["sq"] = {k: pm[k] for k in ("valu_active_share", "lds_active_share", "valu_insts_per_launch", "lds_bank_conflict_share") if k in pm}
+    t_ns = c1["trace_ns"] - c0["trace_ns"]
+    t_launch = max(1, c1["trace_launches"] - c0["trace_launches"])
+    p_rays = c1["photon_rays"] - c0["photon_rays"]
+    t_tflops = 219.0 * p_rays / max(t_ns, 1) / 1e3 if t_ns else 0.0
+    out["roofline_trace"] = {"bound": "valu_f64", "kernel": "k_photon_trace", "achieved": t_tflops, "peak": FP64_PEAK, "unit": "TFLOP/s",
+                             "frac": t_tflops / FP64_PEAK, "launches": int(t_launch), "avg_launch_ms": t_ns / 1e6 / t_launch, "rays_per_launch": p_rays / t_launch,
+                             "note": "rank 0; 219 flop per ray (20 x 10 spheres + 19, SURVEY 8d) x rays cast by photon tracing; the tracer runs on 128 of "
+                                     "1024 workgroup slots, on its own streams, overlapped with the gather: a launch lasts as long as its longest photon path"}
+    if args.spheres > 0:
+        out["roofline_trace"]["note"] = "rank 0; rays cast by photon tracing; the flop figure prices a ray at the Cornell scene's 219 flop (a grid walk tests fewer spheres per ray than brute force, so this is not a flop count for this scene)"
+    if world > 1:
+        ex = r["exchange_ms"]
+        out["rccl_ranks"] = world
+        out["exchanged_bytes_per_pass_per_rank"] = r["exchanged_bytes"] / max(1, args.steps)
+        out["stage_ms"] = {"trace_launch_avg": t_ns / 1e6 / t_launch, "exchange_avg": sum(ex) / len(ex) if ex else None, "gather_launch_avg": g_ns / 1e6 / g_launch,
+                           "note": "rank 0; trace overlaps the gather on its own streams; exchange = export + all-reduce + import of the deposits (rule 1) on the context's stream"}
+    return out
 
 
 def main():
@@ -236,9 +375,11 @@ def main():
     ap.add_argument("--workload", choices=("sppm", "ppm"), default="sppm", help="sppm: BASELINE config 2/3 (the metric's workload); ppm: config 4, classic PPM")
     ap.add_argument("--spheres", type=int, default=0, help="sppm workload: N > 0 replaces the Cornell scene by raytracer_amd.scene.synthetic_spheres(N) "
                     "(BASELINE config 5: --spheres 10000 --width 3840 --height 2160); rays then walk a grid over the spheres")
-    ap.add_argument("--rule", type=int, choices=(0, 1), default=0, help="sppm workload: 0 = the reference's per-photon update (src/sppm2.h:391-421; N > 1: hitpoints "
-                    "partitioned, photon records exchanged); 1 = the per-pass update (src/stochastic_ppm.h:721-741; N > 1: photons sharded, hitpoints "
-                    "replicated, one all-reduce of the fixed-point deposits per pass -- north_star's split)")
+    ap.add_argument("--rule", type=int, choices=(0, 1), default=1,
+                    help="sppm workload, the update rule of the primary line: 1 (default) = the per-pass (N, tau) update (src/stochastic_ppm.h:721-741), "
+                         "north_star's formulation -- N > 1: photons sharded, hitpoints replicated, one all-reduce of the 64-bit fixed-point deposits per pass; "
+                         "0 = the reference's live per-photon update (src/sppm2.h:391-421), exact for any N -- N > 1: hitpoints partitioned, photon records exchanged")
+    ap.add_argument("--one-rule", action="store_true", help="measure only --rule (default at N = 1: the other rule is measured too and reported beside it)")
     ap.add_argument("--supersamples", type=int, default=1, help="--workload ppm only")
     ap.add_argument("--radius2", type=float, default=5.0, help="--workload ppm only: InitialRadius = gather radius (squared), src/main.cpp:76-77")
     args = ap.parse_args()
@@ -274,97 +415,41 @@ def main():
     if args.workload == "ppm":
         return main_ppm(args, rank, world, barrier)
 
-    from raytracer_amd import sppm
-    from raytracer_amd.parallel import ShardedSppm
-
-    W, H, M = args.width, args.height, args.photons
     from raytracer_amd import scene
     table = scene.synthetic_spheres(args.spheres) if args.spheres > 0 else scene.CORNELL_SPHERES
     scene_name = f"{args.spheres}-sphere synthetic scene (scene.synthetic_spheres, seed 20260517) in the Cornell box" if args.spheres > 0 else "Cornell-box"
 
-    if args.warmup > 0:  # untimed: a scratch render of W passes
-        scratch = ShardedSppm(W, H, photons_per_rank=M, rank=rank, world=world, spheres=table, rule=args.rule)
-        scratch.total_passes = args.warmup
-        for i in range(args.warmup):
-            scratch.step(i)
-        scratch.ctx.check()
-        scratch.close()
-    job = ShardedSppm(W, H, photons_per_rank=M, rank=rank, world=world, spheres=table, rule=args.rule)
-    job.total_passes = args.steps
-    job.ctx.set_timing(True)
-    c0 = job.ctx.counters()
-    barrier()
-    t0 = time.perf_counter()
-    progress = os.environ.get("SPPM_BENCH_PROGRESS")
-    for i in range(args.steps):
-        job.step(i)
-        if progress and rank == 0:
-            torch.cuda.synchronize()
-            print(f"[bench] pass {i} done at {time.perf_counter() - t0:.3f} s", file=sys.stderr, flush=True)
-    if world > 1:
-        job.gather_image()   # the final image on every rank: one all-reduce of the ranks' masked images
-    job.ctx.check()   # drains the look-ahead streams too
-    barrier()
-    dt = time.perf_counter() - t0
-    c1 = job.ctx.counters()
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    # per-rank counter deltas summed over ranks (each rank applies updates to its own hitpoints)
-    d = torch.tensor([c1[k] - c0[k] for k in ("rays", "records", "candidates", "updates")], dtype=torch.float64, device="cuda")
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(d, op=dist.ReduceOp.SUM)
-    dt = float(tmax.item())
-    rays, records, cand, upd = [float(x) for x in d.tolist()]
+    primary = run_render(args, rank, world, barrier, args.rule, table, torch, dist)
+    other = None
+    if world == 1 and not args.one_rule:
+        other = run_render(args, rank, world, barrier, 1 - args.rule, table, torch, dist)
 
     if rank == 0:
-        photons_total = float(M) * world * args.steps
-        g_ns = c1["gather_ns"] - c0["gather_ns"]
-        g_launch = max(1, c1["gather_launches"] - c0["gather_launches"])
-        cand0, upd0 = c1["candidates"] - c0["candidates"], c1["updates"] - c0["updates"]
-        # 28 B per candidate hitpoint/record pair examined, +32 B per accepted update
-        alg_bytes = 28.0 * cand0 + 32.0 * upd0
-        achieved = alg_bytes / max(g_ns, 1) if g_ns else 0.0  # bytes/ns == GB/s
-        t_ns = c1["trace_ns"] - c0["trace_ns"]
-        t_launch = max(1, c1["trace_launches"] - c0["trace_launches"])
-        p_rays = c1["photon_rays"] - c0["photon_rays"]
-        tflops = 219.0 * p_rays / max(t_ns, 1) / 1e3 if t_ns else 0.0  # flop/ns = GFLOP/s -> TFLOP/s
-        out = {
-            "metric": "photons traced/sec + hitpoint updates/sec (whole node), SPPM Cornell 1080p",
-            "value": photons_total / dt, "unit": "photons/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{scene_name} SPPM {W}x{H}, {M} photons/pass/GPU, passes 0..{args.steps - 1} "
-                                   f"of a fresh render, alpha 0.7, initial r^2 25, search r^2 25, {'per-photon update (sppm2.h)' if args.rule == 0 else 'per-pass update (stochastic_ppm.h:721-741), deposits in 64-bit fixed point'}, "
-                                   f"XorShift streams", "photons_per_pass": M * world, "width": W, "height": H,
-                       "parallelism": job.describe()},
-            "hitpoint_updates_per_s": upd / dt, "rays_per_s": rays / dt, "records_per_photon": records / max(1.0, float(M) * args.steps * (world if job.replicated_trace else 1)),
-            "updates_per_photon": upd / photons_total,
-            "roofline": {"bound": "hbm", "kernel": "k_gather_tiles" if args.rule == 0 else "k_deposit_tiles", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": None,
-                         "launches": int(g_launch), "avg_launch_ms": g_ns / 1e6 / g_launch,
-                         "alg_bytes_per_launch": alg_bytes / g_launch,
-                         "note": "rank 0; algorithmic bytes = 28 B x (record, hitpoint) pairs distance-tested + 32 B x accepted updates (SURVEY 8d); launch durations from HIP events on the kernel's stream"},
-        }
-        # second fraction asked for by SURVEY 8(d): the intersection work of the photon tracer against the
-        # FP64 vector peak.  The tracer runs on its own stream CONCURRENTLY with the gather, so its launch
-        # durations include the time it shares the CUs.
-        out["roofline_trace"] = {"bound": "valu_f64", "kernel": "k_photon_trace", "achieved": tflops, "peak": 78.6, "unit": "TFLOP/s",
-                                 "frac": tflops / 78.6, "launches": int(t_launch), "avg_launch_ms": t_ns / 1e6 / t_launch,
-                                 "rays_per_launch": p_rays / t_launch,
-                                 "note": "rank 0; 219 flop per ray (20 x 9 spheres + 19, SURVEY 8d) x rays cast by photon tracing; overlapped with the gather"}
-        out["roofline"]["traffic"] = measured_traffic(W, H, M, args.steps) if world == 1 else None  # the PMC passes were made at N = 1
-        bw = measured_stream_bandwidth(torch)
-        out["roofline"]["peak_measured"] = bw
-        out["roofline"]["frac_of_measured"] = achieved / bw
-        out["roofline"]["note"] += "; peak_measured = device-to-device copy of 2 GiB on this box (read + write bytes per second)"
-        if args.spheres > 0:
-            out["roofline_trace"]["note"] = "rank 0; rays cast by photon tracing; the flop figure prices a ray at the Cornell scene's 219 flop (a grid walk tests fewer spheres per ray than brute force, so this is not a flop count for this scene)"
+        body = report(args, world, args.rule, primary, scene_name)
+        out = {"metric": "photons traced/sec + hitpoint updates/sec (whole node), SPPM Cornell 1080p",
+               "value": body.pop("value"), "unit": "photons/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": body.pop("ms_per_step"), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic"}
+        out.update(body)
+        assert bool(torch.isfinite(primary["image"]).all())
+        if other is not None:
+            ob = report(args, world, 1 - args.rule, other, scene_name)
+            key = "per_photon_rule" if args.rule == 1 else "per_pass_rule"
+            a, b = primary["image"], other["image"]
+            rel_rmse = float(torch.sqrt(((a - b) ** 2).mean()) / torch.sqrt((b ** 2).mean()))
+            out[key] = {"value": ob["value"], "unit": "photons/s", "ms_per_step": ob["ms_per_step"], "hitpoint_updates_per_s": ob["hitpoint_updates_per_s"],
+                        "updates_per_photon": ob["updates_per_photon"], "roofline": ob["roofline"], "workload": ob["config"]["workload"],
+                        "image_rel_rmse_between_the_rules": rel_rmse,
+                        "note": "the same render with the other update rule, measured in the same run; the per-photon rule reproduces the reference's own image "
+                                "(tests/test_gpu_reference_stream.py), the per-pass rule is another consistent estimator of the same radiance: after the same number of "
+                                "passes the two images differ by the relative RMSE given here"}
+        out["roofline"]["peak_measured"] = measured_fma_peak(torch)
+        out["roofline"]["frac_of_measured_peak"] = out["roofline"]["achieved"] / out["roofline"]["peak_measured"]
+        out["roofline"]["hbm_copy_GBps_measured"] = measured_stream_bandwidth(torch)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(W, H, M, table=table)
+            out["cpu_baseline"] = cpu_baseline(args.width, args.height, args.photons, args.rule, table=table)
             if args.spheres <= 0:
                 out["cpu_baseline"]["reference_check"] = reference_check()
         print(json.dumps(out), flush=True)
-    job.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -263,6 +263,9 @@ int sppm_download_accepted(sppm_ctx* ctx, uint64_t* h_key, int32_t* h_pix, int64
  * stream it runs on), [12] trace kernel launches timed, [13] rays cast by photon tracing ([0] includes
  * them), [14] the largest number of candidate hitpoints any photon hit had (check_gather_max only), [15] reserved. */
 int sppm_counters(sppm_ctx* ctx, uint64_t h_out[16]);
+/* No counterpart in the reference: the FP64 vector FMA rate (TFLOP/s, an FMA = 2) this device sustains, measured with
+ * a kernel of independent FMA chains -- the measured denominator bench.py prints beside the data-sheet peak. */
+int sppm_measure_fma_peak(void* stream, double* h_tflops);
 int sppm_set_timing(sppm_ctx* ctx, int32_t on);
 
 #ifdef __cplusplus

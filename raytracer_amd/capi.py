@@ -13,7 +13,7 @@ SYMBOLS = [
     "sppm_eye_pass", "sppm_photon_pass", "sppm_trace", "sppm_pack_records", "sppm_append_records", "sppm_gather",
     "sppm_end_pass", "sppm_resolve", "sppm_hdr_pixels", "sppm_save_hdr_file", "sppm_save_ppm_file", "sppm_check",
     "sppm_download_hitpoints", "sppm_download_records", "sppm_owned_mask", "sppm_look_ahead", "sppm_look_ahead_rows", "sppm_rows_ready", "sppm_download_tile_order", "sppm_accept_tap", "sppm_download_accepted", "sppm_counters",
-    "sppm_set_timing", "sppm_intersect_static", "sppm_export_deposits", "sppm_import_deposits", "sppm_fixed_point_scale", "sppm_hitpoint_count", "sppm_download_hitpoint_pixels", "sppm_export_owned_state", "sppm_import_state",
+    "sppm_set_timing", "sppm_measure_fma_peak", "sppm_intersect_static", "sppm_export_deposits", "sppm_import_deposits", "sppm_fixed_point_scale", "sppm_hitpoint_count", "sppm_download_hitpoint_pixels", "sppm_export_owned_state", "sppm_import_state",
 ]
 
 
@@ -82,6 +82,7 @@ def lib():
     L.sppm_download_accepted.argtypes = [vp, vp, vp, C.POINTER(i64)]
     L.sppm_counters.argtypes = [vp, vp]
     L.sppm_set_timing.argtypes = [vp, i32]
+    L.sppm_measure_fma_peak.argtypes = [vp, C.POINTER(C.c_double)]
     L.sppm_export_deposits.argtypes = [vp, vp]
     L.sppm_import_deposits.argtypes = [vp, vp]
     L.sppm_fixed_point_scale.argtypes = [vp, C.POINTER(C.c_double)]

@@ -2029,3 +2029,37 @@ extern "C" int sppm_intersect_static(const sppm_sphere* h_spheres, int32_t n_sph
     if (d_n_hit) HIPCHK(hipMemcpyAsync(d_n_hit, ptr, sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
     return SPPM_OK;
 }
+
+// ================================ measured peak (bench.py) ===========================================
+// No counterpart in the reference.  The FP64 vector FMA rate this device sustains, measured beside the data-sheet
+// figure (SURVEY.md 8d asks for both denominators): every thread runs 8 independent chains of fused multiply-adds.
+__global__ void __launch_bounds__(256) k_fma_peak(double* __restrict__ out, int iters, double a, double b)
+{
+    double x0 = threadIdx.x, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3, x4 = x0 + 4, x5 = x0 + 5, x6 = x0 + 6, x7 = x0 + 7;
+    for (int i = 0; i < iters; i++) {
+        x0 = fma(x0, a, b); x1 = fma(x1, a, b); x2 = fma(x2, a, b); x3 = fma(x3, a, b);
+        x4 = fma(x4, a, b); x5 = fma(x5, a, b); x6 = fma(x6, a, b); x7 = fma(x7, a, b);
+    }
+    const double s = ((x0 + x1) + (x2 + x3)) + ((x4 + x5) + (x6 + x7));
+    if (s == 12345.678) out[0] = s;  // keeps the chains alive; never true for the arguments used
+}
+extern "C" int sppm_measure_fma_peak(void* stream, double* h_tflops)
+{
+    if (!h_tflops) return fail(SPPM_ERR_INVALID, "sppm_measure_fma_peak: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    double* d = nullptr;
+    HIPCHK(hipMalloc((void**)&d, sizeof(double)));
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    const int blocks = 256 * 32, iters = 4096;
+    hipLaunchKernelGGL(k_fma_peak, dim3(blocks), dim3(256), 0, st, d, 64, 0.999999, 1e-7);  // warm-up
+    HIPCHK(hipEventRecord(e0, st));
+    hipLaunchKernelGGL(k_fma_peak, dim3(blocks), dim3(256), 0, st, d, iters, 0.999999, 1e-7);
+    HIPCHK(hipEventRecord(e1, st));
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    *h_tflops = 2.0 * 8.0 * (double)iters * 256.0 * (double)blocks / ((double)ms * 1e-3) / 1e12;
+    hipEventDestroy(e0); hipEventDestroy(e1); hipFree(d);
+    return SPPM_OK;
+}

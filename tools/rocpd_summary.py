@@ -88,8 +88,34 @@ def sq(out_json, dbs):
         print(k, json.dumps(keep[k]))
 
 
+def pmcfile(sq_json, kernel_prefix, out_json, w, h, m, rule, run):
+    """the compact per-kernel file bench.py reads (profiles/r02_pmc_rule<R>.json) from a tools/pmc_passes.sh summary.
+    Shares: persistent wavefronts live about as long as the kernel, so L = SQ_WAVE_CYCLES / SQ_WAVES (units of four
+    cycles, like SQ_ACTIVE_INST_*) is the time every SIMD was occupied; valu_active_share = SQ_ACTIVE_INST_VALU / 1024
+    SIMDs / L; lds_active_share = SQ_LDS_IDX_ACTIVE (cycles) / 256 CUs / 4 L."""
+    k = json.load(open(sq_json))["kernels"]
+    name = next(n for n in k if n.startswith(kernel_prefix))
+    d = k[name]
+    L = d["SQ_WAVE_CYCLES"] / d["SQ_WAVES"]
+    out = {"width": w, "height": h, "photons": m, "rule": rule, "kernel": name, "run": run, "launches": d["launches"],
+           "hbm_bytes_per_launch": d["hbm_bytes_per_launch"],
+           "valu_active_share": d["SQ_ACTIVE_INST_VALU"] / 1024.0 / L,
+           "lds_active_share": d["SQ_LDS_IDX_ACTIVE"] / 256.0 / (4.0 * L),
+           "salu_insts_per_valu_inst": d["SQ_INSTS_SALU"] / d["SQ_INSTS_VALU"],
+           "valu_insts_per_launch": d["SQ_INSTS_VALU"], "lds_insts_per_launch": d["SQ_INSTS_LDS"],
+           "fp64_insts_per_launch": d["SQ_INSTS_VALU_ADD_F64"] + d["SQ_INSTS_VALU_MUL_F64"] + d["SQ_INSTS_VALU_FMA_F64"],
+           "lds_bank_conflict_share": d["SQ_LDS_BANK_CONFLICT"] / max(1.0, d["SQ_LDS_IDX_ACTIVE"]),
+           "wait_inst_any_share": d["SQ_WAIT_INST_ANY"] / d["SQ_WAVE_CYCLES"],
+           "method": "rocprofv3 --pmc, one run per counter group (tools/pmc_passes.sh); per-launch averages; HBM bytes = 2 x FETCH_SIZE (gfx950) + WRITE_SIZE",
+           "counters": d}
+    json.dump(out, open(out_json, "w"), indent=1)
+    print(json.dumps({x: out[x] for x in ("kernel", "hbm_bytes_per_launch", "valu_active_share", "lds_active_share", "wait_inst_any_share")}))
+
+
 if __name__ == "__main__":
-    if sys.argv[1] == "stats":
+    if sys.argv[1] == "pmcfile":
+        pmcfile(sys.argv[2], sys.argv[3], sys.argv[4], int(sys.argv[5]), int(sys.argv[6]), int(sys.argv[7]), int(sys.argv[8]), sys.argv[9])
+    elif sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3])
     elif sys.argv[1] == "sq":
         sq(sys.argv[2], sys.argv[3:])
