@@ -16,7 +16,7 @@ int main(int argc, char** argv)
     const int gahter_max_photon_num = 10000;
     std::stringstream ss;
     ss << "image_ppm_" << width << "_" << height << "_" << samples << "_" << supersamples << "_" << photon_num << "_" << gather_photon_radius;
-    const int rc = photonmap::progressive::render(ss.str(), width, height, samples, supersamples, photon_num, gather_photon_radius, gahter_max_photon_num);
+    const int rc = photonmap::progressive::render(argc > 3 ? std::string(argv[3]) : ss.str(), width, height, samples, supersamples, photon_num, gather_photon_radius, gahter_max_photon_num);
     if (rc) fprintf(stderr, "render failed: %s\n", sppm_last_error());
     return rc ? 1 : 0;
 }

@@ -12,7 +12,8 @@ int main(int argc, char** argv)
     const int photon_num = argc > 2 ? atoi(argv[2]) : 200000;
     photonmap::sppm2::StochasticPpm<width, height> sppm(1, 1);
     sppm.write_pass_files = false;
-    const int rc = sppm.render("image_sppm", width, height, 1, 1, photon_num, 25, 10000, passes);
+    const char* name = argc > 3 ? argv[3] : "image_sppm";  // output prefix: <name>.ppm, <name>.hdr
+    const int rc = sppm.render(name, width, height, 1, 1, photon_num, 25, 10000, passes);
     if (rc) fprintf(stderr, "render failed: %s\n", sppm_last_error());
     return rc ? 1 : 0;
 }
