@@ -57,14 +57,13 @@ typedef struct sppm_config {
     double alpha;            /* src/sppm2.h:39 */
     double initial_radius2;  /* src/sppm2.h:44 */
     double gather_radius2;   /* render()'s gather_photon_radius; a SQUARED bound (src/kdtree.h:57,126) */
-    int64_t gather_max;      /* render()'s gahter_max_photon_num; the kd search's K cap (src/kdtree.h:58).
-                                This build implements the uncapped set, which is the reference's set
-                                as long as no photon hit has more than K candidate hitpoints (the
-                                capped search depends on the order of the reference's kd traversal,
-                                DESIGN.md 3a).  With check_gather_max != 0 every gather first counts
-                                each query's candidates exactly (brute force over all hitpoints: a
-                                validation mode, O(records x hitpoints)); sppm_check() then reports
-                                SPPM_ERR_OVERFLOW if any exceeded K, sppm_counters [14] the largest. */
+    int64_t gather_max;      /* render()'s gahter_max_photon_num; the kd search's K cap (src/kdtree.h:58,126-133).
+                                Enforced exactly (check_gather_max = 0, the default): whenever K is below the number of
+                                hitpoints, every photon hit walks the reference's tree -- built on the host with the
+                                reference's std::sort from the reference's vector order, uploaded per eye pass -- with
+                                the reference's heap, and the pairs the cap drops are withheld from the gather
+                                (raytracer_amd/csrc/sppm_cap.hpp).  update_rule 0 and classic PPM; seconds per pass
+                                at 1080p, nothing when K >= the number of hitpoints.  See check_gather_max. */
     int32_t update_rule;     /* 0: per-photon shrink, src/sppm2.h:391-421 (default, the live SPPM)
                                 1: per-pass (N, tau) update, src/stochastic_ppm.h:721-741: photons deposit into
                                    per-hitpoint accumulators (:439-456) kept in 64-bit fixed point (exact integer
@@ -81,7 +80,11 @@ typedef struct sppm_config {
     int32_t tile_first, tile_stride; /* this rank gathers for the 8x8 pixel tiles tile_first + k*tile_stride
                                         (tiles numbered row-major over the image-index grid); 0,0 = all tiles.
                                         The eye pass and tracing always cover what the calls ask for. */
-    int32_t check_gather_max;
+    int32_t check_gather_max; /* 0: enforce gather_max (above).  1: do not enforce; count each query's candidates by brute
+                                 force over all hitpoints (O(records x hitpoints), validation only) and let sppm_check()
+                                 report SPPM_ERR_OVERFLOW if any exceeded K (sppm_counters [14] = the largest count).
+                                 2: ignore gather_max -- the uncapped set {d2 < R^2, |dt| <= 0.01 R^2}; a deviation from
+                                 the reference wherever a query has more than K candidates, chosen explicitly (bench.py). */
     int32_t sampler;         /* 0: one edupt::XorShift stream (src/random.h:9-33) per (pass, pixel) and per photon --
                                 the parallel, GPU-count independent definition (default).
                                 1: the reference's own sampler (src/sampler/value_sampler.h:8-15): ONE sequential
@@ -261,7 +264,8 @@ int sppm_download_accepted(sppm_ctx* ctx, uint64_t* h_key, int32_t* h_pix, int64
  * timing is on), [7] gather kernel launches timed, [8] in-region candidates staged, [9] staging rounds,
  * [10] live tile launches, [11] nanoseconds of device time in the photon-trace kernel (HIP events on the
  * stream it runs on), [12] trace kernel launches timed, [13] rays cast by photon tracing ([0] includes
- * them), [14] the largest number of candidate hitpoints any photon hit had (check_gather_max only), [15] reserved. */
+ * them), [14] check_gather_max 1: the largest number of candidate hitpoints any photon hit had; otherwise the photon hits
+ * whose search the K cap acted on, [15] the (record, hitpoint) pairs the cap withheld from the gather. */
 int sppm_counters(sppm_ctx* ctx, uint64_t h_out[16]);
 /* No counterpart in the reference: the FP64 vector FMA rate (TFLOP/s, an FMA = 2) this device sustains, measured with
  * a kernel of independent FMA chains -- the measured denominator bench.py prints beside the data-sheet peak. */

@@ -14,6 +14,26 @@ __device__ __forceinline__ long long fx_fix(double v, double scale, bool& clampe
     return __double2ll_rn(x);
 }
 
+// Pairs (photon-hit record, hitpoint) that the reference's K-capped search dropped (sppm_cap.hpp): an open-addressing
+// table of (record key, hitpoint) entries, filled before the gather starts and only read by it.  n == nullptr or
+// *n == 0: no pair is dropped (the cap cannot act, or did not), and the gathers never look.
+struct Veto { unsigned long long* tab; unsigned long long mask; const unsigned long long* n; };
+__device__ __forceinline__ unsigned long long veto_hash(unsigned long long key, unsigned int pix)
+{
+    unsigned long long h = key * 0x9E3779B97F4A7C15ull ^ ((unsigned long long)pix + 1ull) * 0xC2B2AE3D27D4EB4Full;
+    h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
+    return h;
+}
+__device__ __forceinline__ bool veto_active(const Veto& v) { return v.n != nullptr && *v.n != 0ull; }
+__device__ __forceinline__ bool veto_has(const Veto& v, unsigned long long key, int pix)
+{
+    for (unsigned long long h = veto_hash(key, (unsigned int)pix) & v.mask;; h = (h + 1ull) & v.mask) {
+        const unsigned long long k = v.tab[2 * h];
+        if (k == 0ull) return false;  // record keys are > 0 (depth >= 1)
+        if (k == key && v.tab[2 * h + 1] == (unsigned long long)pix) return true;
+    }
+}
+
 // max over valid hitpoints of min(r2, gather_r2), as an ordered-int atomic max on the bit pattern
 struct Own { const uint8_t* mask; };  // mask[p] != 0: this rank owns pixel p
 __device__ __forceinline__ bool owned(const Own& o, int p) { return o.mask[p] != 0; }
@@ -36,6 +56,7 @@ __global__ void k_r2max(HpArrays hp, Own own, double gather_r2, unsigned long lo
 struct GatherParams {
     Grid g; double gather_r2, alpha; int rule; Own own; double fx_scale; int32_t* err;
     int unit_weight;  // classic PPM: the record's flux is applied as it is (no hitpoint weight or colour)
+    Veto veto;
     uint64_t* tap_key; int32_t* tap_pix; unsigned long long* tap_n; int64_t tap_cap;
 };
 
@@ -65,6 +86,7 @@ __global__ void __launch_bounds__(256) k_gather(HpArrays hp, DevScene sc, RecArr
     if (t < hp.P) {
         const int p = t;
         const int P = hp.P;
+        const bool vetoes = veto_active(gp.veto);
         if (hp.valid[p] && owned(gp.own, p)) {
             const d3 hpos = mk(hp.pos[p], hp.pos[P + p], hp.pos[2 * P + p]);
             const d3 hn = mk(hp.nrm[p], hp.nrm[P + p], hp.nrm[2 * P + p]);
@@ -117,6 +139,7 @@ __global__ void __launch_bounds__(256) k_gather(HpArrays hp, DevScene sc, RecArr
                     last = sk[j];
                     // the radius may have shrunk since the scan: test again with the current one
                     if (!rec_accept(rec, r, sk[j], hpos, hn, r2, gp.gather_r2)) continue;
+                    if (vetoes && veto_has(gp.veto, sk[j], p)) continue;  // dropped by the K cap of the reference's search
                     const int64_t c = rec.cap;
                     const d3 pf = mk(rec.f[6 * c + r], rec.f[7 * c + r], rec.f[8 * c + r]);
                     if (gp.rule == 0) {  // src/sppm2.h:397-419

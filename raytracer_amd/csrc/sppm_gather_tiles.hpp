@@ -38,6 +38,7 @@ struct TileParams {
     int n_pix, n_owned;    // entries of order[]; virtual tiles = ceil(n_pix / 64)
     double cluster_d;      // lanes farther than this (max norm) from a tile's seed lane are replayed separately
     uint64_t* tap_key; int32_t* tap_pix; unsigned long long* tap_n; int64_t tap_cap;
+    Veto veto;  // pairs dropped by the reference's K cap (sppm_cap.hpp); the ordered gather only
     unsigned long long* item_times;  // diagnostic (SPPM_ITEM_TIMES): start/end clock of every work item
 };
 
@@ -418,6 +419,7 @@ __global__ void __launch_bounds__(256) GATHER_WAVES_ATTR k_gather_tiles(HpArrays
     // reaches the break).
     const unsigned int n_items = q[0];
     const unsigned int n_waves = gridDim.x * 4u;
+    const bool vetoes = veto_active(tp.veto);
     for (bool first_item = true;; first_item = false) {
     unsigned int item_i = blockIdx.x * 4u + (unsigned int)wv;
     if (!first_item) {
@@ -623,7 +625,8 @@ __global__ void __launch_bounds__(256) GATHER_WAVES_ATTR k_gather_tiles(HpArrays
                     const d3 dir = hpos - mk(row[0], row[1], row[2]);
                     const d3 ff = mk(row[7], row[8], row[9]);
                     const double d2 = len2(dir);
-                    const bool take = has && (d2 <= r2);
+                    bool take = has && (d2 <= r2);
+                    if (vetoes && take) take = !veto_has(tp.veto, (unsigned long long)__double_as_longlong(row[6]), p);
                     if (__ballot(take) != 0ull) {  // src/sppm2.h:397-419
                         const double na = n * tp.alpha;
                         double g = (na + tp.alpha) / (na + 1.0);

@@ -30,6 +30,7 @@
 #include <mutex>
 #include <random>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "sppm_device.hpp"
@@ -40,6 +41,7 @@
 #include "sppm_trace.hpp"
 #include "sppm_records.hpp"
 #include "sppm_gather_simple.hpp"
+#include "sppm_cap.hpp"
 #include "sppm_image.hpp"
 #include "sppm_exchange.hpp"
 #include "sppm_gather_tiles.hpp"
@@ -149,6 +151,14 @@ struct sppm_ctx {
     unsigned long long snap_prev[24]; int snap_prev_valid; long gather_j; int64_t hist_S[4], hist_B[4];
     uint32_t n_buckets;
     int64_t batch_photons;
+    // K cap of the reference's search (sppm_cap.hpp): the reference's hitpoint vector in the order its tree leaves it
+    // (host), the same on the device, one heap per search lane, the table of dropped pairs the gathers consult
+    std::vector<int32_t> kd_order; std::vector<uint8_t> kd_listed; int kd_pass, kd_fallback;
+    int32_t* d_kd; int64_t kd_cap;
+    double* d_heap_d2; int32_t* d_heap_pix; int64_t heap_cap_d, heap_cap_x;
+    unsigned long long* d_veto_tab; int64_t veto_entries; unsigned long long *d_veto_n, *d_cap_stat;
+    Veto veto_dev;  // what the gathers get: n == nullptr while the cap cannot act
+    uint64_t cap_queries, cap_capped, cap_nodes, cap_vetoes, cap_max_fill;
     // accept tap
     uint64_t* d_tap_key; int32_t* d_tap_pix; unsigned long long* d_tap_n; int64_t tap_cap;
     // timing of the gather kernel
@@ -566,6 +576,11 @@ extern "C" int sppm_destroy(sppm_ctx* c)
     if (c->h_rows_n) hipHostFree(c->h_rows_n);
     if (c->ev_rows) hipEventDestroy(c->ev_rows);
     for (int b = 0; b < 2; b++) if (c->ev_stat[b]) hipEventDestroy(c->ev_stat[b]);
+    if (c->d_kd) hipFree(c->d_kd);
+    if (c->d_heap_d2) hipFree(c->d_heap_d2);
+    if (c->d_heap_pix) hipFree(c->d_heap_pix);
+    if (c->d_veto_tab) hipFree(c->d_veto_tab);
+    if (c->d_veto_n) { hipFree(c->d_veto_n); hipFree(c->d_cap_stat); }
     if (c->d_u_eye) hipFree(c->d_u_eye);
     if (c->d_u_lens) hipFree(c->d_u_lens);
     if (c->d_u_ph) hipFree(c->d_u_ph);
@@ -1138,6 +1153,7 @@ static int gather_simple(sppm_ctx* c)
     gp.g = g; gp.gather_r2 = c->cfg.gather_radius2; gp.alpha = c->cfg.alpha; gp.rule = c->cfg.update_rule;
     gp.own = own_of(c); gp.unit_weight = c->algo; gp.fx_scale = c->fx_scale; gp.err = c->d_err;
     gp.tap_key = c->d_tap_key; gp.tap_pix = c->d_tap_pix; gp.tap_n = c->d_tap_n; gp.tap_cap = c->tap_cap;
+    gp.veto = c->veto_dev;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->timing) { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventRecord(e0, st)); }
     hipLaunchKernelGGL(k_gather, dim3(nblk(c->P, 256)), dim3(256), 0, st, c->hp, scene_of(c), c->rec_s, c->d_cell_start, gp, c->d_counters);
@@ -1289,6 +1305,7 @@ static int gather_tiles(sppm_ctx* c)
     tp.tap_key = c->d_tap_key; tp.tap_pix = c->d_tap_pix; tp.tap_n = c->d_tap_n; tp.tap_cap = c->tap_cap;
     tp.g = g;
     tp.cluster_d = c->gs.cluster_d;
+    tp.veto = c->veto_dev;
     const double cell = 1.0 / g.inv_c;
     const int64_t S = g.S, B = g.B;
     c->hist_S[c->gather_j & 3] = S; c->hist_B[c->gather_j & 3] = B; c->gather_j++;
@@ -1444,15 +1461,127 @@ static int deposit_tiles(sppm_ctx* c)
     return SPPM_OK;
 }
 
+// ---- K cap, host side (sppm_cap.hpp) --------------------------------------------------------------------
+// The reference's tree: KDTree::BalanceKDTreeNode (src/kdtree.h:165-198) sorts a range of its vector with std::sort on
+// one coordinate, takes the middle as the node, and recurses into the halves.  The same std::sort (this is libstdc++'s,
+// as in the reference's build) on the same sequence with the same comparison leaves the same permutation, ties
+// included -- so the vector is kept here as the reference keeps it: a hitpoint is appended when its pixel first finds
+// one, in render order (src/sppm2.h:204-209, the y/x loops of :625-646), and every pass sorts the vector in place from
+// the order the pass before left (kdtree.h:87).  Classic PPM builds once from the list's order.  Subtrees below the
+// first levels are sorted by separate threads (their ranges are disjoint).
+static void cap_sort_range(int32_t* v, const double* pos, int64_t P, int begin, int end, int depth, int par_levels)
+{
+    if (end - begin <= 0) return;
+    const double* ax = pos + (int64_t)(depth % 3) * P;
+    std::sort(v + begin, v + end, [ax](int32_t a, int32_t b) { return ax[a] < ax[b]; });
+    const int mid = begin + (end - begin) / 2;
+    if (par_levels > 0 && end - begin > 4096) {
+        std::thread t(cap_sort_range, v, pos, P, begin, mid, depth + 1, par_levels - 1);
+        cap_sort_range(v, pos, P, mid + 1, end, depth + 1, par_levels - 1);
+        t.join();
+    } else {
+        cap_sort_range(v, pos, P, begin, mid, depth + 1, 0);
+        cap_sort_range(v, pos, P, mid + 1, end, depth + 1, 0);
+    }
+}
+static int cap_build_tree(sppm_ctx* c)
+{
+    if (c->kd_pass == c->last_eye_pass && !c->kd_order.empty()) return 0;
+    const int64_t P = c->P;
+    HIPCHK(hipStreamSynchronize(c->eye_stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    std::vector<int32_t> valid((size_t)P);
+    std::vector<double> pos((size_t)P * 3);
+    HIPCHK(hipMemcpy(valid.data(), c->hp.valid, (size_t)P * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(pos.data(), c->hp.pos, (size_t)P * 24, hipMemcpyDeviceToHost));
+    if (c->kd_listed.size() != (size_t)P) { c->kd_listed.assign((size_t)P, 0); c->kd_order.clear(); }
+    if (c->algo == 1) {
+        if (c->kd_order.empty()) for (int64_t i = 0; i < P; i++) if (valid[(size_t)i]) c->kd_order.push_back((int32_t)i);
+    } else {
+        const int W = c->cfg.width, H = c->cfg.height;
+        for (int y = 0; y < H; y++)
+            for (int x = 0; x < W; x++) {
+                const int index = (H - y - 1) * W + x;
+                if (valid[(size_t)index] && !c->kd_listed[(size_t)index]) { c->kd_listed[(size_t)index] = 1; c->kd_order.push_back(index); }
+            }
+    }
+    const int n = (int)c->kd_order.size();
+    cap_sort_range(c->kd_order.data(), pos.data(), P, 0, n, 0, 4);
+    if (grow(c, &c->d_kd, &c->kd_cap, std::max<int64_t>(n, 1))) return SPPM_ERR_HIP;
+    HIPCHK(hipMemcpy(c->d_kd, c->kd_order.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    c->kd_pass = c->last_eye_pass;
+    return 0;
+}
+// the capped search of every record in the current buffer; leaves the dropped pairs in the Veto table
+static int cap_search(sppm_ctx* c)
+{
+    if (c->cfg.update_rule == 1)
+        return fail(SPPM_ERR_INVALID, "gather_max is below the number of hitpoints, so the reference's K cap could act; the exact capped search is built for update_rule 0 (set check_gather_max = 2 to run the per-pass rule uncapped)");
+    int rc = cap_build_tree(c);
+    if (rc) return rc;
+    const int n = (int)c->kd_order.size();
+    if (c->cfg.gather_max >= (int64_t)n) return 0;  // fewer hitpoints than K: no heap can overflow
+    hipStream_t st = c->stream;
+    const int64_t K = c->cfg.gather_max;
+    if (K < 0) return fail(SPPM_ERR_INVALID, "gather_max is negative");
+    const int64_t stride = K + 1;
+    const int64_t budget = env_i64("SPPM_CAP_HEAP_MB", 4096) << 20;
+    int64_t lanes = std::min<int64_t>(65536, std::max<int64_t>(64, budget / (12 * stride)));
+    lanes = std::min<int64_t>(lanes, (c->rec_u.cap + 63) / 64 * 64);
+    lanes = std::max<int64_t>(64, lanes / 64 * 64);
+    if (grow(c, &c->d_heap_d2, &c->heap_cap_d, lanes * stride) || grow(c, &c->d_heap_pix, &c->heap_cap_x, lanes * stride)) return SPPM_ERR_HIP;
+    if (!c->d_veto_n) { HIPCHK(hipMalloc((void**)&c->d_veto_n, 8)); HIPCHK(hipMalloc((void**)&c->d_cap_stat, 32)); }
+    for (int attempt = 0;; attempt++) {
+        if (!c->d_veto_tab) {
+            if (c->veto_entries < (1 << 16)) c->veto_entries = 1 << 16;
+            HIPCHK(hipMalloc((void**)&c->d_veto_tab, (size_t)c->veto_entries * 16));
+        }
+        HIPCHK(hipMemsetAsync(c->d_veto_tab, 0, (size_t)c->veto_entries * 16, st));
+        HIPCHK(hipMemsetAsync(c->d_veto_n, 0, 8, st));
+        HIPCHK(hipMemsetAsync(c->d_cap_stat, 0, 32, st));
+        CapParams cp;
+        memset(&cp, 0, sizeof cp);
+        cp.kd = c->d_kd; cp.n = n; cp.R0 = c->cfg.gather_radius2; cp.K = K;
+        cp.heap_d2 = c->d_heap_d2; cp.heap_pix = c->d_heap_pix; cp.heap_stride = stride; cp.lanes = (int)lanes;
+        cp.veto.tab = c->d_veto_tab; cp.veto.mask = (unsigned long long)c->veto_entries - 1ull; cp.veto.n = c->d_veto_n;
+        cp.veto_n = c->d_veto_n; cp.veto_cap = (unsigned long long)c->veto_entries / 2ull;
+        cp.stat = c->d_cap_stat; cp.own = own_of(c);
+        hipLaunchKernelGGL(k_cap_search, dim3((unsigned)(lanes / 64)), dim3(64), 0, st, c->hp, c->rec_u, c->d_rec_count, cp, c->d_err);
+        HIPCHK(hipGetLastError());
+        unsigned long long got = 0, stat[4] = {0, 0, 0, 0};
+        HIPCHK(hipMemcpyAsync(&got, c->d_veto_n, 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(stat, c->d_cap_stat, 32, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (got <= cp.veto_cap) {
+            c->cap_capped += stat[0]; c->cap_nodes += stat[1]; c->cap_max_fill = std::max<uint64_t>(c->cap_max_fill, stat[2]); c->cap_vetoes += got;
+            c->veto_dev = cp.veto;
+            if (getenv("SPPM_DEBUG")) fprintf(stderr, "[sppm] K cap: %llu queries capped, %llu nodes walked, %llu pairs dropped (table %lld entries, %lld lanes)\n", stat[0], stat[1], got, (long long)c->veto_entries, (long long)lanes);
+            return 0;
+        }
+        if (attempt >= 2) return fail(SPPM_ERR_OVERFLOW, "K cap: the table of dropped pairs could not be sized");
+        int64_t need = 1 << 16;
+        while ((unsigned long long)need < got * 5ull / 2ull) need <<= 1;  // fill of at most 0.4
+        hipFree(c->d_veto_tab); c->d_veto_tab = nullptr;
+        c->veto_entries = need;
+    }
+}
+
 // grid build + ordered gather over whatever is in the unsorted record buffer; clears the buffer
 extern "C" int sppm_gather(sppm_ctx* c)
 {
     if (!c) return fail(SPPM_ERR_INVALID, "sppm_gather: null context");
     CTX_DEVICE(c, "sppm_gather");
-    if (c->cfg.check_gather_max && c->P > 0 && c->rec_end != c->rec_first) {
+    if (c->cfg.check_gather_max == 1 && c->P > 0 && c->rec_end != c->rec_first) {
         hipLaunchKernelGGL(k_count_queries, dim3(nblk(c->rec_u.cap, 256)), dim3(256), 0, c->stream, c->hp, c->rec_u, c->d_rec_count, c->cfg.gather_radius2,
                            (long long)c->cfg.gather_max, c->d_err, c->d_qmax);
         HIPCHK(hipGetLastError());
+    }
+    c->veto_dev.n = nullptr;
+    // check_gather_max 0 (default): the K cap is enforced, exactly, whenever it could act (K below the number of
+    // hitpoints in the tree); 1: counted only (above); 2: ignored (the uncapped set, a documented deviation)
+    if (c->cfg.check_gather_max == 0 && c->cfg.gather_max < (int64_t)c->P && c->P > 0 && c->rec_end != c->rec_first) {
+        int rc = cap_search(c);
+        if (rc) return rc;
     }
     if (!c->gather_mode) return gather_simple(c);
     return c->cfg.update_rule == 1 ? deposit_tiles(c) : gather_tiles(c);
@@ -1711,10 +1840,11 @@ extern "C" int sppm_check(sppm_ctx* c)
     if (rc) return rc;
     if (err[0]) return fail(SPPM_ERR_OVERFLOW, "record buffer overflow: raise SPPM_RECORD_CAP or lower SPPM_BATCH_PHOTONS");
     if (err[1]) return fail(SPPM_ERR_OVERFLOW, "a photon path exceeded 32767 bounces");
-    if (err[2]) return fail(SPPM_ERR_OVERFLOW, "a photon hit had more than gather_max candidate hitpoints: the reference's K cap would have acted, which this build does not reproduce (sppm_counters [14] has the largest count)");
+    if (err[2]) return fail(SPPM_ERR_OVERFLOW, "a photon hit had more than gather_max candidate hitpoints: the reference's K cap would have acted (check_gather_max = 1 only counts; 0 enforces the cap; sppm_counters [14] has the largest count)");
     if (err[3]) return fail(SPPM_ERR_STATE, "a record's photon index lies outside the range declared for the batch");
     if (err[4]) return fail(SPPM_ERR_OVERFLOW, "reference-stream mode: a path ran past the uploaded part of the stream");
     if (err[5]) return fail(SPPM_ERR_STATE, "reference-stream mode: a pixel consumed a different number of draws than the offset walk found");
+    if (err[7]) return fail(SPPM_ERR_OVERFLOW, "K cap: the walk of the hitpoint tree ran out of stack");
     if (err[6]) return fail(SPPM_ERR_OVERFLOW, "per-pass rule: a deposit left the fixed-point range (a photon flux above 8192 x the emitted flux, or 2^21 deposits on one hitpoint in one pass)");
     return SPPM_OK;
 }
@@ -1929,7 +2059,7 @@ extern "C" int sppm_counters(sppm_ctx* c, uint64_t h_out[16])
     h_out[0] = d[0] + d[1]; h_out[1] = c->photons_traced; h_out[2] = c->records_total + d[2]; h_out[3] = d[3]; h_out[4] = d[4];
     h_out[5] = c->gather_batches; h_out[6] = c->gather_ns; h_out[7] = c->gather_launches;
     h_out[8] = d[5]; h_out[9] = d[6]; h_out[10] = d[7]; h_out[11] = c->trace_ns; h_out[12] = c->trace_launches; h_out[13] = d[1];
-    h_out[14] = qmax; h_out[15] = 0;
+    h_out[14] = c->cfg.check_gather_max == 1 ? qmax : c->cap_capped; h_out[15] = c->cap_vetoes;
     return SPPM_OK;
 }
 

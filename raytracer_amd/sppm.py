@@ -44,7 +44,9 @@ def make_config(width, height, *, samples=1, supersamples=1, camera_position=sce
     cfg.sampler = sampler  # 0: XorShift streams; 1: the reference's sequential mt19937 streams
     # 0: PinholeCamera; 1: thin lens (DoFCamera, src/cameras.h:66-139; src/sppm2.h:73-79 has aperture 4, focus 180)
     cfg.camera_model, cfg.aperture, cfg.focus_dist, cfg.seed_lens = camera_model, aperture, focus_dist, seed_lens
-    cfg.check_gather_max = check_gather_max  # count every query's candidates exactly and report if any exceeds gather_max (slow)
+    # 0: the reference's K cap is enforced exactly whenever it could act (gather_max below the number of hitpoints);
+    # 1: only count every query's candidates and report if any exceeds gather_max (brute force); 2: ignore the cap
+    cfg.check_gather_max = check_gather_max
     cfg.algorithm = algorithm  # 0: sppm2.h (stochastic); 1: progressive_photonmapping.h (classic PPM, a list of hitpoints)
     cfg.ownership = ownership  # with tile_stride > 1 -- 0: 8x8 screen tiles round-robin; 1: ranges of the hitpoints' Morton order
     return cfg
@@ -230,7 +232,10 @@ class SppmContext:
         capi.check(self.L.sppm_counters(self.h, out.ctypes.data))
         names = ("rays", "photons", "records", "candidates", "updates", "gather_batches", "gather_ns", "gather_launches",
                  "selected", "rounds", "tile_launches", "trace_ns", "trace_launches", "photon_rays", "max_query_candidates")
-        return {k: int(v) for k, v in zip(names, out)}
+        d = {k: int(v) for k, v in zip(names, out)}
+        # [14] is the largest candidate count under check_gather_max = 1, else the queries the K cap acted on; [15] the pairs it dropped
+        d["cap_queries"], d["cap_dropped_pairs"] = int(out[14]), int(out[15])
+        return d
 
     def set_timing(self, on=True):
         capi.check(self.L.sppm_set_timing(self.h, 1 if on else 0))

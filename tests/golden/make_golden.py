@@ -129,10 +129,12 @@ def main():
     run("64x48_dof", 64, 48, 20000, 2, 1024, 25.0, 100000, 1000, 2000, False, dof=(4.0, 180.0, 3000))
     # several eye paths per pixel: samples = 2, supersamples = 2 (the last path's hitpoint stays, the direct terms add up)
     run("64x48_spp", 64, 48, 20000, 2, 1024, 25.0, 100000, 1000, 2000, False, spp=(2, 2))
-    # the K cap of the kd search BINDS (K = 50 and 300 against ~3000 hitpoints): src/kdtree.h:126-133 drops the farthest
-    # entry and tightens both tests for the rest of the walk, so the accepted sets depend on the tree's visiting order
-    run("64x48_k50", 64, 48, 20000, 3, 4096, 25.0, 50, 1000, 2000, False)
-    run("64x48_k300", 64, 48, 20000, 2, 2048, 25.0, 300, 31, 77, False)
+    # the K cap of the kd search BINDS (at 64x48 a query sees ~25 hitpoints, at 320x240 ~600): src/kdtree.h:126-133 drops
+    # the farthest entry and tightens both tests for the rest of the walk, so the accepted sets depend on the tree's
+    # visiting order
+    run("64x48_k3", 64, 48, 20000, 3, 4096, 25.0, 3, 1000, 2000, False)
+    run("64x48_k8", 64, 48, 20000, 2, 2048, 25.0, 8, 31, 77, False)
+    run("320x240_k100", 320, 240, 50000, 2, 512, 25.0, 100, 1000, 2000, False)
     # tag, W, H, photons, per-photon-traced, search r^2 (= InitialRadius, main.cpp:76-77), K cap, seeds, supersamples
     run_ppm("64x48", 64, 48, 20000, 4096, 25.0, 100000, 1000, 2000, 1)
     run_ppm("48x36_ss2_r5", 48, 36, 30000, 2048, 5.0, 100000, 31, 77, 2)

@@ -34,7 +34,7 @@ def test_stateless_pieces(golden):
     _bits(ol.to_int(g["encode_in"]).reshape(-1, 3), g["encode_toint"], "to_int")
 
 
-@pytest.mark.parametrize("tag", ["64x48", "64x48_r5", "320x240", "64x48_dof", "64x48_spp", "64x48_k50", "64x48_k300"])
+@pytest.mark.parametrize("tag", ["64x48", "64x48_r5", "320x240", "64x48_dof", "64x48_spp", "64x48_k3", "64x48_k8", "320x240_k100"])
 def test_sppm_passes(golden, tag):
     g = golden(tag)
     w, h, photons, passes, traced, k, se, sp = [int(x) for x in g["meta"]]
