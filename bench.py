@@ -249,6 +249,28 @@ def measured_counters(width, height, photons, rule, steps):
     return t
 
 
+def k_cap_enforced(width, height, photons, table, torch, passes=2):
+    """The timed renders run UNCAPPED (gather_max out of reach; config.gather_max says so).  BASELINE config 2 passes
+    K = 10000 to the kd search, which acts on a few percent of the photon hits at 1080p: this measures the same render
+    with the cap ENFORCED exactly (sppm_config.check_gather_max = 0, raytracer_amd/csrc/sppm_cap.hpp) over `passes`
+    passes of the per-photon rule, and what the cap did."""
+    from raytracer_amd import sppm
+    ctx = sppm.SppmContext(sppm.make_config(width, height, photons_per_pass=photons, gather_max=10000), spheres=table)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(passes):
+        ctx.eye_pass(i); ctx.photon_pass(i, photons); ctx.end_pass()
+    ctx.check()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    c = ctx.counters()
+    ctx.close()
+    return {"gather_max": 10000, "passes": passes, "photons_per_s": passes * photons / dt, "ms_per_pass": 1e3 * dt / passes,
+            "photon_hits": c["records"], "photon_hits_capped": c["cap_queries"], "pairs_withheld": c["cap_dropped_pairs"], "updates": c["updates"],
+            "note": "per-photon rule with the reference's K cap enforced bit-exactly (tests/test_gpu_k_cap.py): host-built kd order + one search lane "
+                    "per photon hit; a fidelity mode, not the timed path"}
+
+
 # algorithmic work of the gather kernels (DESIGN.md section 5)
 PAIR_FLOP = 23.0      # FP64 operations of one (record, hitpoint) test: 3 sub, 5 |d|^2, 5 n.g, 5 g.d, 5 flatness with its band
 UPDATE_FLOP = {0: 24.0, 1: 0.0}   # per accepted update: rule 0 = shrink factor, 3 x (w c f / pi), (acc + add) g; rule 1 = integer adds only
@@ -319,7 +341,7 @@ def report(args, world, rule, r, table_name):
         "value": photons_total / dt, "ms_per_step": 1e3 * dt / args.steps,
         "config": {"workload": f"{table_name} SPPM {W}x{H}, {M} photons/pass/GPU, passes 0..{args.steps - 1} of a fresh render, alpha 0.7, "
                                f"initial r^2 25, search r^2 25, {rule_name}, XorShift streams",
-                   "update_rule": rule, "photons_per_pass": M * world, "width": W, "height": H, "parallelism": r["describe"]},
+                   "update_rule": rule, "gather_max": "not enforced (uncapped search; K = 10000 enforced: see k_cap)", "photons_per_pass": M * world, "width": W, "height": H, "parallelism": r["describe"]},
         "hitpoint_updates_per_s": upd / dt, "rays_per_s": rays / dt,
         "records_per_photon": records / max(1.0, float(M) * args.steps * (world if r["replicated_trace"] else 1)),
         "updates_per_photon": upd / photons_total,
@@ -372,6 +394,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--photons", type=int, default=1_000_000, help="photons per pass per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-k-cap", action="store_true", help="skip the two passes with the reference's K cap enforced (N = 1)")
     ap.add_argument("--workload", choices=("sppm", "ppm"), default="sppm", help="sppm: BASELINE config 2/3 (the metric's workload); ppm: config 4, classic PPM")
     ap.add_argument("--spheres", type=int, default=0, help="sppm workload: N > 0 replaces the Cornell scene by raytracer_amd.scene.synthetic_spheres(N) "
                     "(BASELINE config 5: --spheres 10000 --width 3840 --height 2160); rays then walk a grid over the spheres")
@@ -445,6 +468,8 @@ def main():
         out["roofline"]["peak_measured"] = measured_fma_peak(torch)
         out["roofline"]["frac_of_measured_peak"] = out["roofline"]["achieved"] / out["roofline"]["peak_measured"]
         out["roofline"]["hbm_copy_GBps_measured"] = measured_stream_bandwidth(torch)
+        if world == 1 and not args.no_k_cap and args.spheres <= 0:
+            out["k_cap"] = k_cap_enforced(args.width, args.height, args.photons, table, torch)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.width, args.height, args.photons, args.rule, table=table)
             if args.spheres <= 0:

@@ -193,6 +193,14 @@ int sppm_look_ahead(sppm_ctx* ctx, int32_t pass, int64_t first, int64_t count);
  * there and returns their number; d_rows may then be read on any stream.  No counterpart in the reference. */
 int sppm_look_ahead_rows(sppm_ctx* ctx, int32_t pass, int64_t first, int64_t count, double* d_rows, int64_t cap_rows);
 int sppm_rows_ready(sppm_ctx* ctx, int64_t* n);
+/* The same with the rows sorted by DESTINATION rank, for an all-to-all exchange (no counterpart in the reference).
+ * Needs tile_stride > 1 with ownership 1: the eye pass is replicated, so every rank knows where every rank's hitpoints
+ * lie and keeps a coarse occupancy map per rank.  d_rows is [tile_stride][cap_rows][10]; block d receives the records
+ * whose cell in rank d's map (of the eye pass of `pass`) is set -- a superset of what d will use, d filters again with
+ * its own map in sppm_append_records.  sppm_rows_ready_to blocks the host until the rows are there and returns the
+ * number of rows of each block in h_counts[tile_stride]. */
+int sppm_look_ahead_rows_to(sppm_ctx* ctx, int32_t pass, int64_t first, int64_t count, double* d_rows, int64_t cap_rows);
+int sppm_rows_ready_to(sppm_ctx* ctx, int64_t* h_counts);
 int sppm_gather(sppm_ctx* ctx);
 int sppm_pack_records(sppm_ctx* ctx, double* d_rows, int64_t cap_rows, int64_t* n);
 int sppm_append_records(sppm_ctx* ctx, const double* d_rows, int64_t n, int64_t photon_first, int64_t photon_end);

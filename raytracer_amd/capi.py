@@ -12,7 +12,7 @@ SYMBOLS = [
     "sppm_last_error", "sppm_device_count", "sppm_create", "sppm_destroy", "sppm_camera_rays", "sppm_intersect",
     "sppm_eye_pass", "sppm_photon_pass", "sppm_trace", "sppm_pack_records", "sppm_append_records", "sppm_gather",
     "sppm_end_pass", "sppm_resolve", "sppm_hdr_pixels", "sppm_save_hdr_file", "sppm_save_ppm_file", "sppm_check",
-    "sppm_download_hitpoints", "sppm_download_records", "sppm_owned_mask", "sppm_look_ahead", "sppm_look_ahead_rows", "sppm_rows_ready", "sppm_download_tile_order", "sppm_accept_tap", "sppm_download_accepted", "sppm_counters",
+    "sppm_download_hitpoints", "sppm_download_records", "sppm_owned_mask", "sppm_look_ahead", "sppm_look_ahead_rows", "sppm_rows_ready", "sppm_look_ahead_rows_to", "sppm_rows_ready_to", "sppm_download_tile_order", "sppm_accept_tap", "sppm_download_accepted", "sppm_counters",
     "sppm_set_timing", "sppm_measure_fma_peak", "sppm_intersect_static", "sppm_export_deposits", "sppm_import_deposits", "sppm_fixed_point_scale", "sppm_hitpoint_count", "sppm_download_hitpoint_pixels", "sppm_export_owned_state", "sppm_import_state",
 ]
 
@@ -78,6 +78,8 @@ def lib():
     L.sppm_look_ahead.argtypes = [vp, i32, i64, i64]
     L.sppm_look_ahead_rows.argtypes = [vp, i32, i64, i64, vp, i64]
     L.sppm_rows_ready.argtypes = [vp, C.POINTER(i64)]
+    L.sppm_look_ahead_rows_to.argtypes = [vp, i32, i64, i64, vp, i64]
+    L.sppm_rows_ready_to.argtypes = [vp, C.POINTER(i64)]
     L.sppm_accept_tap.argtypes = [vp, i64]
     L.sppm_download_accepted.argtypes = [vp, vp, vp, C.POINTER(i64)]
     L.sppm_counters.argtypes = [vp, vp]

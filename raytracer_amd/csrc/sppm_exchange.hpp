@@ -89,6 +89,63 @@ __global__ void k_mark_near(HpArrays hp, const int32_t* __restrict__ pix, int n,
             for (int ix = x0; ix <= x1; ix++) cells[(iz * NEAR_DIM + iy) * NEAR_DIM + ix] = 1;
 }
 
+// seeds of `n` bounding boxes: min slots all ones, max slots zero (ordered-int doubles)
+__global__ void k_bb_seed(unsigned long long* __restrict__ bb, int n)
+{
+    for (int i = threadIdx.x; i < 6 * n; i += blockDim.x) bb[i] = (i % 6) < 3 ? ~0ull : 0ull;
+}
+
+// k_pack_records by destination: block d of `rows` ([world][cap_rows][10]) gets the records whose cell of rank d's map
+// is set (cells_all == nullptr: every record goes to every rank).  The records are read once per destination.
+__global__ void __launch_bounds__(256) k_pack_records_to(RecArrays rec, const unsigned long long* __restrict__ rec_count, double* __restrict__ rows, int64_t cap_rows,
+                                                         unsigned long long* __restrict__ n_out, int world, const unsigned long long* __restrict__ bb_all,
+                                                         const uint8_t* __restrict__ cells_all, double reach)
+{
+    __shared__ double s_row[4][64 * 10];
+    const int64_t n = min((int64_t)*rec_count, rec.cap);
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t w0 = ((int64_t)blockIdx.x * 4 + wv) * WAVE_ROWS;
+    if (w0 >= n) return;
+    for (int d = 0; d < world; d++) {
+        NearMap nm;
+        nm.bb = bb_all ? bb_all + 6 * d : nullptr; nm.cells = cells_all ? cells_all + (size_t)d * NEAR_DIM * NEAR_DIM * NEAR_DIM : nullptr; nm.reach = reach;
+        unsigned long long keep[WAVE_ROWS / 64];
+        int total = 0;
+#pragma unroll
+        for (int g = 0; g < WAVE_ROWS / 64; g++) {
+            const int64_t i = w0 + g * 64 + lane;
+            bool has = i < n && rec.key[i] != REC_INVALID;
+            if (has && nm.cells) has = near_rank(nm, rec.f[i], rec.f[rec.cap + i], rec.f[2 * rec.cap + i]);
+            keep[g] = __ballot(has);
+            total += __popcll(keep[g]);
+        }
+        if (total == 0) continue;
+        unsigned long long at = 0;
+        if (lane == 0) at = atomicAdd(&n_out[d], (unsigned long long)total);
+        at = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(at >> 32)) << 32) |
+             (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)at);
+        double* out = rows + (int64_t)d * cap_rows * 10;
+#pragma unroll
+        for (int g = 0; g < WAVE_ROWS / 64; g++) {
+            const unsigned long long m = keep[g];
+            if (m == 0) continue;
+            const int64_t i = w0 + g * 64 + lane;
+            const int cnt = __popcll(m);
+            if ((m >> lane) & 1ull) {
+                double* r = s_row[wv] + 10 * __popcll(m & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
+                r[0] = __longlong_as_double((long long)rec.key[i]);
+#pragma unroll
+                for (int c = 0; c < 9; c++) r[1 + c] = rec.f[c * rec.cap + i];
+            }
+            __builtin_amdgcn_wave_barrier();
+            const int64_t fit = min((int64_t)cnt, max((int64_t)0, cap_rows - (int64_t)at));  // the count is complete either way
+            for (int64_t j = lane; j < fit * 10; j += 64) out[(int64_t)at * 10 + j] = s_row[wv][j];
+            __builtin_amdgcn_wave_barrier();
+            at += (unsigned long long)cnt;
+        }
+    }
+}
+
 // nm.cells != nullptr: rows that cannot matter to this rank (near_rank) are not stored.
 __global__ void __launch_bounds__(256) k_append_records(RecArrays rec, unsigned long long* __restrict__ rec_count, const double* __restrict__ rows, int64_t n,
                                                         int32_t* __restrict__ err, NearMap nm)

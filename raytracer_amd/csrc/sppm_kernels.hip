@@ -117,6 +117,12 @@ struct sppm_ctx {
     struct { int valid, pass; } pre_eye;  // an eye pass computed ahead of its call
     int last_eye_pass;
     unsigned long long *d_rows_n, *h_rows_n; hipEvent_t ev_rows; int rows_pending; int64_t rows_cap;  // sppm_look_ahead_rows
+    // Record exchange by destination (sppm_look_ahead_rows_to): with spatial ownership every rank knows every rank's
+    // hitpoints (the eye pass is replicated), so it keeps, per view, the occupancy map of EVERY rank and sends a record
+    // only to the ranks whose map holds its cell.  d_all_pix: the first eye pass's whole Morton order (rank r owns
+    // positions [r P/N, (r+1) P/N)).
+    int all_maps; int32_t* d_all_pix; uint8_t* d_near_all_v[2]; unsigned long long* d_bb_all_v[2]; int view_pass[2]; hipEvent_t ev_view[2];
+    unsigned long long *d_rows_n_to, *h_rows_n_to;  // [tile_stride]
     RecArrays rec_u, rec_s;  // unsorted (traced / received), sorted by bucket
     unsigned long long* d_rec_count;
     unsigned long long* d_counters;  // 8: [0] rays [3] candidates [4] updates [5] selected [6] rounds [7] live tile launches
@@ -528,6 +534,17 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
         c->d_hp_bb = c->d_hp_bb_r[0];
         TRY(dev_alloc(c, &c->d_near_v[0], (size_t)NEAR_DIM * NEAR_DIM * NEAR_DIM)); TRY(dev_alloc(c, &c->d_near_v[1], (size_t)NEAR_DIM * NEAR_DIM * NEAR_DIM)); c->d_near = c->d_near_v[0];
         TRY(dev_alloc(c, &c->d_own_mask, P, false));  // every byte is written by the upload below
+        c->all_maps = c->own_pending && c->gather_mode;
+        c->view_pass[0] = c->view_pass[1] = -1;
+        for (int v = 0; v < 2; v++)
+            if (hipEventCreateWithFlags(&c->ev_view[v], hipEventDisableTiming) != hipSuccess) { sppm_destroy(c); return fail(SPPM_ERR_HIP, "creating events failed"); }
+        if (c->all_maps) {
+            const size_t N = (size_t)c->tile_stride;
+            TRY(dev_alloc(c, &c->d_all_pix, P, false));
+            for (int v = 0; v < 2; v++) { TRY(dev_alloc(c, &c->d_near_all_v[v], N * NEAR_DIM * NEAR_DIM * NEAR_DIM)); TRY(dev_alloc(c, &c->d_bb_all_v[v], N * 6)); }
+            TRY(dev_alloc(c, &c->d_rows_n_to, N));
+            if (hipHostMalloc((void**)&c->h_rows_n_to, N * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) { sppm_destroy(c); return fail(SPPM_ERR_HIP, "pinned memory for the row counts"); }
+        }
         std::vector<uint8_t> mask(P, 0);  // lives until the stream synchronisation at the end of sppm_create
         for (int32_t p : own) mask[(size_t)p] = 1;
         // both uploads on the context's stream, like everything else here (a caller's non-blocking stream is not ordered with the null stream)
@@ -574,6 +591,8 @@ extern "C" int sppm_destroy(sppm_ctx* c)
     for (void* p : c->allocs) hipFree(p);
     if (c->h_stat) hipHostFree(c->h_stat);
     if (c->h_rows_n) hipHostFree(c->h_rows_n);
+    if (c->h_rows_n_to) hipHostFree(c->h_rows_n_to);
+    for (int v = 0; v < 2; v++) if (c->ev_view[v]) hipEventDestroy(c->ev_view[v]);
     if (c->ev_rows) hipEventDestroy(c->ev_rows);
     for (int b = 0; b < 2; b++) if (c->ev_stat[b]) hipEventDestroy(c->ev_stat[b]);
     if (c->d_kd) hipFree(c->d_kd);
@@ -848,6 +867,7 @@ static int eye_launch(sppm_ctx* c, int32_t pass, hipStream_t st)
             // the binning drop the records far from the rank's hitpoints.
             const int64_t lo = (int64_t)c->tile_first * c->P / c->tile_stride, hi = (int64_t)(c->tile_first + 1) * c->P / c->tile_stride;
             const int n = (int)(hi - lo);
+            if (c->all_maps) HIPCHK(hipMemcpyAsync(c->d_all_pix, c->d_order_r[slot], (size_t)c->P * 4, hipMemcpyDeviceToDevice, st));
             if (n > 0) {
                 HIPCHK(hipMemcpyAsync(c->d_own_pix, c->d_order_r[slot] + lo, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
                 HIPCHK(hipMemcpyAsync(c->d_order_r[slot], c->d_own_pix, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
@@ -867,8 +887,25 @@ static int eye_launch(sppm_ctx* c, int32_t pass, hipStream_t st)
             hipLaunchKernelGGL(k_mark_near, dim3(nblk(c->n_own_pix, 256)), dim3(256), 0, st, c->view[nv], c->d_own_pix, c->n_own_pix, c->d_hp_bb_r[slot], reach_of(c), c->cfg.gather_radius2, c->d_near_v[nv]);
             HIPCHK(hipGetLastError());
         }
+        if (c->all_maps && !c->own_pending) {  // every rank's bounding box and occupancy map, for the exchange by destination
+            const int N = c->tile_stride;
+            hipLaunchKernelGGL(k_bb_seed, dim3(1), dim3(64), 0, st, c->d_bb_all_v[nv], N);
+            HIPCHK(hipMemsetAsync(c->d_near_all_v[nv], 0, (size_t)N * NEAR_DIM * NEAR_DIM * NEAR_DIM, st));
+            for (int pass2 = 0; pass2 < 2; pass2++)
+                for (int r = 0; r < N; r++) {
+                    const int64_t lo = (int64_t)r * c->P / N, hi = (int64_t)(r + 1) * c->P / N;
+                    const int n = (int)(hi - lo);
+                    if (n <= 0) continue;
+                    if (pass2 == 0) hipLaunchKernelGGL(k_hp_bbox, dim3(std::min(nblk(n, 256), 512)), dim3(256), 0, st, c->view[nv], c->d_all_pix + lo, n, c->d_bb_all_v[nv] + 6 * r);
+                    else hipLaunchKernelGGL(k_mark_near, dim3(nblk(n, 256)), dim3(256), 0, st, c->view[nv], c->d_all_pix + lo, n, c->d_bb_all_v[nv] + 6 * r, reach_of(c), c->cfg.gather_radius2,
+                                            c->d_near_all_v[nv] + (size_t)r * NEAR_DIM * NEAR_DIM * NEAR_DIM);
+                }
+            HIPCHK(hipGetLastError());
+        }
         HIPCHK(hipEventRecord(c->ev_order[slot], st));
     }
+    c->view_pass[nv] = pass;
+    HIPCHK(hipEventRecord(c->ev_view[nv], st));
     return 0;
 }
 
@@ -1045,11 +1082,60 @@ extern "C" int sppm_look_ahead_rows(sppm_ctx* c, int32_t pass, int64_t first, in
 extern "C" int sppm_rows_ready(sppm_ctx* c, int64_t* n)
 {
     if (!c || !n) return fail(SPPM_ERR_INVALID, "sppm_rows_ready: null argument");
-    if (!c->rows_pending) return fail(SPPM_ERR_STATE, "sppm_rows_ready: no sppm_look_ahead_rows is outstanding");
+    if (c->rows_pending != 1) return fail(SPPM_ERR_STATE, "sppm_rows_ready: no sppm_look_ahead_rows is outstanding");
     HIPCHK(hipEventSynchronize(c->ev_rows));
     c->rows_pending = 0;
     *n = (int64_t)*c->h_rows_n;
     if (*n > c->rows_cap) return fail(SPPM_ERR_OVERFLOW, "sppm_rows_ready: the row buffer was too small (n holds the count needed)");
+    return SPPM_OK;
+}
+
+// sppm_look_ahead_rows with the rows sorted by DESTINATION: d_rows is [tile_stride][cap_rows][10], block d holds the
+// records rank d can need -- those whose cell of rank d's occupancy map (made by the eye pass of `pass`, which every
+// rank runs) is set.  A superset of what d will use; d applies its own map again when it appends them.  If the eye pass
+// of `pass` has not been started on this context yet, every record goes to every rank.
+extern "C" int sppm_look_ahead_rows_to(sppm_ctx* c, int32_t pass, int64_t first, int64_t count, double* d_rows, int64_t cap_rows)
+{
+    if (!c || !d_rows || cap_rows < 0) return fail(SPPM_ERR_INVALID, "sppm_look_ahead_rows_to: bad argument");
+    CTX_DEVICE(c, "sppm_look_ahead_rows_to");
+    if (!c->all_maps) return fail(SPPM_ERR_STATE, "sppm_look_ahead_rows_to: needs several ranks with spatial ownership (tile_stride > 1, ownership 1) and the tile gather");
+    if (c->sampler == 1) return fail(SPPM_ERR_STATE, "sppm_look_ahead_rows_to: the sequential reference stream cannot run ahead");
+    c->rows_pending = 0;
+    int rc = sppm_look_ahead(c, pass, first, count);  // starts the eye pass of `pass` too, if it is the next one
+    if (rc) return rc;
+    const int nb = count > 0 ? c->pre.buf : (c->cur + 1) % NBUF;
+    hipStream_t ts = TSTREAM(c, nb);
+    const int N = c->tile_stride;
+    int v = -1;
+    if (!c->own_pending) {
+        if (c->last_eye_pass == pass && c->view_pass[c->cur_view] == pass) v = c->cur_view;
+        else if (c->pre_eye.valid && c->pre_eye.pass == pass && c->view_pass[1 - c->cur_view] == pass) v = 1 - c->cur_view;
+    }
+    if (v >= 0) HIPCHK(hipStreamWaitEvent(ts, c->ev_view[v], 0));
+    HIPCHK(hipMemsetAsync(c->d_rows_n_to, 0, (size_t)N * sizeof(unsigned long long), ts));
+    if (count > 0) {
+        hipLaunchKernelGGL(k_pack_records_to, dim3(nblk(c->rec_buf[nb].cap, 4 * WAVE_ROWS)), dim3(256), 0, ts, c->rec_buf[nb], c->d_rec_count_buf[nb], d_rows, cap_rows, c->d_rows_n_to, N,
+                           v >= 0 ? c->d_bb_all_v[v] : (const unsigned long long*)nullptr, v >= 0 ? c->d_near_all_v[v] : (const uint8_t*)nullptr, reach_of(c));
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemsetAsync(c->d_rec_count_buf[nb], 0, sizeof(unsigned long long), ts));  // the records live in the rows now
+        c->pre.valid = 0;
+    }
+    HIPCHK(hipMemcpyAsync(c->h_rows_n_to, c->d_rows_n_to, (size_t)N * sizeof(unsigned long long), hipMemcpyDeviceToHost, ts));
+    HIPCHK(hipEventRecord(c->ev_rows, ts));
+    c->rows_pending = 2; c->rows_cap = cap_rows;
+    return SPPM_OK;
+}
+
+// waits for the rows of sppm_look_ahead_rows_to; h_counts[tile_stride]: rows in each destination's block
+extern "C" int sppm_rows_ready_to(sppm_ctx* c, int64_t* h_counts)
+{
+    if (!c || !h_counts) return fail(SPPM_ERR_INVALID, "sppm_rows_ready_to: null argument");
+    if (c->rows_pending != 2) return fail(SPPM_ERR_STATE, "sppm_rows_ready_to: no sppm_look_ahead_rows_to is outstanding");
+    HIPCHK(hipEventSynchronize(c->ev_rows));
+    c->rows_pending = 0;
+    bool over = false;
+    for (int d = 0; d < c->tile_stride; d++) { h_counts[d] = (int64_t)c->h_rows_n_to[d]; over |= h_counts[d] > c->rows_cap; }
+    if (over) return fail(SPPM_ERR_OVERFLOW, "sppm_rows_ready_to: a destination's row block was too small (h_counts holds the counts needed)");
     return SPPM_OK;
 }
 

@@ -10,8 +10,12 @@ What shards and what does not (DESIGN.md "Multi-GPU"):
     bins the records near its region); 0 = 8x8 pixel tiles dealt round-robin.
   * Photon tracing is independent per photon (streams keyed by global photon index).  Two ways to
     give every rank all records of a pass:
-      exchange="allgather" (default): every batch is a contiguous photon range cut into one block per rank; the packed records
-          (1.58 x 80 bytes per photon) are combined with one RCCL all-gather per batch.
+      exchange="alltoall" (default with ownership 1): every batch is a contiguous photon range cut into one block per rank;
+          a rank sorts the records of its block by DESTINATION -- the eye pass is replicated, so every rank keeps a coarse
+          occupancy map of every rank's hitpoints and knows which ranks can use a record -- and one RCCL all-to-all per
+          batch delivers to each rank only the records near its hitpoints (80 bytes each).
+      exchange="allgather": the same blocks, every rank's records to every rank with one all-gather per batch
+          (1.58 x 80 bytes per photon of the whole batch arrive at every rank); the receiver drops what is far.
       exchange="replicate": every rank traces all photons of the pass itself.  No data-path
           collective, but the tracing does not scale (measured: it is the bottleneck from 2 ranks on).
   * The image: every rank resolves its own hitpoints, zeroes the rest, one all-reduce (x + 0 is exact).
@@ -47,11 +51,13 @@ class ShardedSppm:
         if rule not in (0, 1):
             raise ValueError("rule must be 0 (per-photon update, sppm2.h) or 1 (per-pass update, stochastic_ppm.h)")
         if exchange is None:
-            exchange = "allreduce" if rule == 1 else "allgather"
+            exchange = "allreduce" if rule == 1 else ("alltoall" if ownership == 1 and world > 1 else "allgather")
         if rule == 1 and exchange != "allreduce":
             raise ValueError("rule 1 exchanges the per-hitpoint accumulators: exchange='allreduce'")
-        if rule == 0 and exchange not in ("replicate", "allgather"):
-            raise ValueError("rule 0: exchange must be 'replicate' or 'allgather'")
+        if rule == 0 and exchange not in ("replicate", "allgather", "alltoall"):
+            raise ValueError("rule 0: exchange must be 'replicate', 'allgather' or 'alltoall'")
+        if exchange == "alltoall" and (ownership != 1 or world < 2):
+            raise ValueError("exchange='alltoall' needs several ranks with spatial ownership (ownership=1)")
         self.W, self.H, self.P = width, height, width * height
         self.rank, self.world = rank, world
         self.M_rank = photons_per_rank
@@ -130,8 +136,12 @@ class ShardedSppm:
         if self._rows is None:
             cap = 4 * (self.batch_photons // self.world) + 4096
             dev = self.ctx.device
-            self._rows = [torch.empty((cap, 10), dtype=torch.float64, device=dev) for _ in range(2)]
+            if self.exchange == "alltoall":  # one block of rows per destination
+                self._rows = [torch.empty((self.world, cap, 10), dtype=torch.float64, device=dev) for _ in range(2)]
+            else:
+                self._rows = [torch.empty((cap, 10), dtype=torch.float64, device=dev) for _ in range(2)]
             self._all = [torch.empty((self.world * cap, 10), dtype=torch.float64, device=dev) for _ in range(2)]
+            self._cap = cap
             self._side = torch.cuda.Stream(device=dev)
 
     def _where(self, i):
@@ -142,17 +152,39 @@ class ShardedSppm:
         """trace this rank's block of the batch (and the eye pass of pass i, if it is the next one) on the context's
         look-ahead streams and pack it into rows[buf]"""
         p, base = self._where(i)
-        self.ctx.look_ahead_rows(p, base + done + self.rank * n, n, self._rows[buf])
+        if self.exchange == "alltoall":
+            self.ctx.look_ahead_rows_to(p, base + done + self.rank * n, n, self._rows[buf])
+        else:
+            self.ctx.look_ahead_rows(p, base + done + self.rank * n, n, self._rows[buf])
+
+    def _exchange_alltoall(self, i, done, n, buf):
+        """wait for the block's rows, then the counts (one small all-gather) and ONE all-to-all of the ragged blocks on the
+        side stream: rank s's records for this rank land at recv[s * cap : s * cap + got[s]]"""
+        import torch
+        send = self.ctx.rows_ready_to()
+        cap = self._cap
+        with torch.cuda.stream(self._side):
+            table = exchange_count_rows(send, self.world, self.ctx.device)   # table[s][d]: rows rank s holds for rank d
+            got = [table[s][self.rank] for s in range(self.world)]
+            if max(got) > cap:
+                raise RuntimeError("record exchange: a block received from another rank exceeds the row buffer")
+            rows, recv = self._rows[buf], self._all[buf]
+            all_to_all_rows([recv[s * cap:s * cap + got[s]] for s in range(self.world)], [rows[d, :send[d]] for d in range(self.world)], self.rank)
+        self.exchanged_bytes += 80 * sum(got[s] for s in range(self.world) if s != self.rank)
+        self._next = dict(key=(i, done, n), counts=got, m=cap, buf=buf)
 
     def _exchange(self, i, done, n, buf):
         """wait for the block's rows, then one all-gather (padded to the largest count) on the side stream"""
         import torch
         import torch.distributed as dist
+        if self.exchange == "alltoall":
+            return self._exchange_alltoall(i, done, n, buf)
         cnt = self.ctx.rows_ready()
         with torch.cuda.stream(self._side):
             counts = exchange_counts(cnt, self.world, self.ctx.device)
             m = max(1, int(max(counts)))
             all_gather_into(self._all[buf][:self.world * m], self._rows[buf][:m])
+        self.exchanged_bytes += 80 * m * (self.world - 1)   # received from the other ranks, padding included
         self._next = dict(key=(i, done, n), counts=counts, m=m, buf=buf)
 
     def _photon_pass_allgather(self, i):
@@ -261,7 +293,7 @@ def _host_staged(t):
 
 def _pinned_like(t):
     import torch
-    return torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    return torch.empty(t.shape, dtype=t.dtype, pin_memory=t.is_cuda)
 
 
 def all_gather_into(out, inp):
@@ -284,6 +316,47 @@ def all_reduce_sum(t):
         t.copy_(h)
     else:
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
+
+
+def all_to_all_rows(out_list, in_list, rank):
+    """ragged all-to-all: in_list[d] goes to rank d, out_list[s] receives rank s's block (sizes agreed beforehand).
+    RCCL: one grouped all_to_all.  gloo (rehearsal): point-to-point through pinned host memory."""
+    import torch
+    import torch.distributed as dist
+    if dist.get_backend() != "gloo":
+        dist.all_to_all(out_list, in_list)
+        return
+    world = len(in_list)
+    out_list[rank].copy_(in_list[rank])
+    h_in = [None if d == rank else _pinned_like(in_list[d]).copy_(in_list[d]) for d in range(world)]
+    h_out = [None if s == rank else _pinned_like(out_list[s]) for s in range(world)]
+    if any(t.is_cuda for t in in_list):
+        torch.cuda.current_stream().synchronize()
+    ops = []
+    for k in range(1, world):   # the same pairing order on every rank
+        d, s = (rank + k) % world, (rank - k) % world
+        if h_in[d].numel():
+            ops.append(dist.P2POp(dist.isend, h_in[d], d))
+        if h_out[s].numel():
+            ops.append(dist.P2POp(dist.irecv, h_out[s], s))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    for s in range(world):
+        if s != rank and h_out[s].numel():
+            out_list[s].copy_(h_out[s])
+
+
+def exchange_count_rows(counts, world, device):
+    """all-gather `world` integers per rank: returns table[s][d] = counts of rank s"""
+    import torch
+    import torch.distributed as dist
+    if dist.get_backend() == "gloo":
+        device = "cpu"
+    mine = torch.tensor(list(counts), dtype=torch.int64, device=device)
+    out = torch.empty((world * world,), dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(out, mine)
+    return out.view(world, world).tolist()
 
 
 def exchange_counts(count, world, device):

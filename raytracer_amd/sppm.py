@@ -115,6 +115,15 @@ class SppmContext:
     def look_ahead_rows(self, i, first, count, rows):
         capi.check(self.L.sppm_look_ahead_rows(self.h, i, first, count, rows.data_ptr(), rows.shape[0]))
 
+    def look_ahead_rows_to(self, i, first, count, rows):
+        """rows: device tensor [world][cap][10]; block d gets the records rank d can need (sppm_look_ahead_rows_to)"""
+        capi.check(self.L.sppm_look_ahead_rows_to(self.h, i, first, count, rows.data_ptr(), rows.shape[1]))
+
+    def rows_ready_to(self):
+        n = (C.c_int64 * max(1, int(self.cfg.tile_stride)))()
+        capi.check(self.L.sppm_rows_ready_to(self.h, n))
+        return [int(x) for x in n]
+
     def rows_ready(self):
         n = C.c_int64()
         capi.check(self.L.sppm_rows_ready(self.h, C.byref(n)))

@@ -67,7 +67,7 @@ def main():
     img = job.gather_image().cpu().numpy()
     hp = job.ctx.hitpoints()
     mask = job.ctx.owned_mask().cpu().numpy()
-    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), image=img, n=hp["n"], r2=hp["r2"], flux=hp["flux"], mask=mask)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), image=img, n=hp["n"], r2=hp["r2"], flux=hp["flux"], mask=mask, exchanged=job.exchanged_bytes)
     job.close()
     dist.destroy_process_group()
 

@@ -35,11 +35,14 @@ def _single(W, H, M, passes):
     return img, hp
 
 
-@pytest.mark.parametrize("exchange,ownership", [("allgather", 1), ("replicate", 0), ("allgather", 0)])
+_EXCHANGED = {}
+
+
+@pytest.mark.parametrize("exchange,ownership", [("allgather", 1), ("alltoall", 1), ("replicate", 0), ("allgather", 0)])
 def test_two_ranks_equal_one_gpu(tmp_path, exchange, ownership):
     world, W, H, M_rank, passes = 2, 96, 64, 24000, 3
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    port = 29600 + os.getpid() % 1000 + (0 if exchange == "allgather" else 1) + 2 * ownership
+    port = 29600 + os.getpid() % 1000 + {"allgather": 0, "replicate": 1, "alltoall": 4}[exchange] + 2 * ownership
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker_gpu.py"), str(tmp_path), exchange, str(ownership)]
     res = _run(cmd, env)
@@ -56,6 +59,11 @@ def test_two_ranks_equal_one_gpu(tmp_path, exchange, ownership):
             merged[m] = g[k][m]
         a, b = np.ascontiguousarray(merged), np.ascontiguousarray(ref[k])
         assert (a.view(np.uint64) == b.view(np.uint64)).all() if a.dtype.kind == "f" else (a == b).all(), k
+    _EXCHANGED[(exchange, ownership)] = [int(g["exchanged"]) for g in got]
+    if ("allgather", 1) in _EXCHANGED and ("alltoall", 1) in _EXCHANGED:
+        # sorted by destination, a rank receives only the records near its hitpoints: fewer bytes than the all-gather brings
+        assert sum(_EXCHANGED[("alltoall", 1)]) < sum(_EXCHANGED[("allgather", 1)]), _EXCHANGED
+        assert min(_EXCHANGED[("alltoall", 1)]) > 0
 
 
 def test_two_ranks_per_pass_rule_equal_one_gpu(tmp_path):
