@@ -381,7 +381,8 @@ def report(args, world, rule, r, table_name):
         out["rccl_ranks"] = world
         out["exchanged_bytes_per_pass_per_rank"] = r["exchanged_bytes"] / max(1, args.steps)
         out["stage_ms"] = {"trace_launch_avg": t_ns / 1e6 / t_launch, "exchange_avg": sum(ex) / len(ex) if ex else None, "gather_launch_avg": g_ns / 1e6 / g_launch,
-                           "note": "rank 0; trace overlaps the gather on its own streams; exchange = export + all-reduce + import of the deposits (rule 1) on the context's stream"}
+                           "note": "rank 0; trace overlaps the gather on its own streams; exchange = " + ("export + all-reduce + import of the deposits, per pass, on the context's stream" if rule == 1 else
+                                    "counts + the record collective (all-to-all by destination, or all-gather), per batch, on a side stream beside the gather")}
     return out
 
 

@@ -125,6 +125,20 @@ class ShardedSppm:
             ev[1].record()
             self.stage_events.append(("exchange",) + ev)
 
+    def _stage_begin(self):
+        """events around an exchange on the current stream (time_stages): device time of the collective as enqueued"""
+        if not self.time_stages:
+            return None
+        import torch
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+        return ev
+
+    def _stage_end(self, ev):
+        if ev:
+            ev[1].record()
+            self.stage_events.append(("exchange",) + ev)
+
     # ---- all-gather exchange, pipelined --------------------------------------------------------------------
     def _batch_size(self, done):
         """photons per rank of the batch that starts at photon `done` of a pass (same rule on every rank)"""
@@ -164,12 +178,14 @@ class ShardedSppm:
         send = self.ctx.rows_ready_to()
         cap = self._cap
         with torch.cuda.stream(self._side):
+            ev = self._stage_begin()
             table = exchange_count_rows(send, self.world, self.ctx.device)   # table[s][d]: rows rank s holds for rank d
             got = [table[s][self.rank] for s in range(self.world)]
             if max(got) > cap:
                 raise RuntimeError("record exchange: a block received from another rank exceeds the row buffer")
             rows, recv = self._rows[buf], self._all[buf]
             all_to_all_rows([recv[s * cap:s * cap + got[s]] for s in range(self.world)], [rows[d, :send[d]] for d in range(self.world)], self.rank)
+            self._stage_end(ev)
         self.exchanged_bytes += 80 * sum(got[s] for s in range(self.world) if s != self.rank)
         self._next = dict(key=(i, done, n), counts=got, m=cap, buf=buf)
 
@@ -181,9 +197,11 @@ class ShardedSppm:
             return self._exchange_alltoall(i, done, n, buf)
         cnt = self.ctx.rows_ready()
         with torch.cuda.stream(self._side):
+            ev = self._stage_begin()
             counts = exchange_counts(cnt, self.world, self.ctx.device)
             m = max(1, int(max(counts)))
             all_gather_into(self._all[buf][:self.world * m], self._rows[buf][:m])
+            self._stage_end(ev)
         self.exchanged_bytes += 80 * m * (self.world - 1)   # received from the other ranks, padding included
         self._next = dict(key=(i, done, n), counts=counts, m=m, buf=buf)
 
