@@ -261,11 +261,29 @@ __global__ void __launch_bounds__(256) DEP_ATTR k_deposit_tiles(HpArrays hp, Rec
         lim_lo[h] = inc[h] ? lim * (1.0 - 1e-13) : -1.0; lim_hi[h] = inc[h] ? lim * (1.0 + 1e-13) : -1.0;  // -1: never inside, never too close to call
         ax[h] = ay[h] = az[h] = 0; am[h] = 0;
     }
+    // Whole-cluster bounds for the two tests that do not involve the radius (DEP_H == 1).  The 64 hitpoints of a cluster
+    // lie within a fraction of a unit of each other, nearly always on one surface: for most staged records the normal
+    // test and the flatness test come out the same for EVERY hitpoint of the cluster.  One lane per staged record
+    // decides that from the cluster's bounding box and the spread of its normals, with margins far above rounding --
+    // where a bound holds, each lane's exact test is known to pass (or fail), so the outcome is the exact one:
+    //   rejected by all (normal or flatness fails for the whole cluster): the record is skipped;
+    //   "easy" (both pass for the whole cluster): only the distance test is left for the lanes -- half the arithmetic
+    //   and two thirds of the LDS reads of the full test, which the rest of the records still take.
+    double ndev = 0.0;
+    d3 nbar = mk(0, 0, 0);
+    const double bcx = 0.5 * (R.bx0 + R.bx1), bcy = 0.5 * (R.by0 + R.by1), bcz = 0.5 * (R.bz0 + R.bz1);
+    const double bex = (0.5 * (R.bx1 - R.bx0)) * (1.0 + 1e-12) + 1e-12, bey = (0.5 * (R.by1 - R.by0)) * (1.0 + 1e-12) + 1e-12, bez = (0.5 * (R.bz1 - R.bz0)) * (1.0 + 1e-12) + 1e-12;
+    if (DEP_H == 1) {
+        const int seed = __ffsll((long long)ballot64(inc[0])) - 1;
+        nbar = mk(rl_d(hn[0].x, seed), rl_d(hn[0].y, seed), rl_d(hn[0].z, seed));
+        ndev = sqrt(wave_max_d(inc[0] ? len2(hn[0] - nbar) : 0.0)) * (1.0 + 1e-9) + 1e-15;
+    }
     st_count += DSTAMP() - ts_setup;
     unsigned int c_sel = 0, c_round = 0;
     unsigned long long c_pairs = 0;
+    unsigned long long d_easy = 0, d_rej = 0, d_full = 0; (void)d_rej;  // diagnostic build: staged records by class
     bool clamped = false;
-    int sel_n = 0;
+    int sel_n = 0, n_easy = 0, n_full = 0;
     // iterator over the list in groups of 64 entries
     int qbase = -64;
     unsigned int voff = 0, cbase = 0, i_end = 0;
@@ -323,34 +341,84 @@ __global__ void __launch_bounds__(256) DEP_ATTR k_deposit_tiles(HpArrays hp, Rec
         if (pend) {
             const unsigned long long t0 = DSTAMP();
             // the pending group: keep what lies within rmax of the cluster's bounding box (a hitpoint of the cluster
-            // can only accept such records), compact it into the staging rows, and start the loads of the next group
-            bool in = false;
+            // can only accept such records), sort it by class (see above: dropped / distance test only / full test)
+            // while each lane still holds its record in registers, compact it into the staging rows -- "easy" records
+            // from row 0 up, the others from row 63 down -- and start the loads of the next group
+            bool in = false, easy = false;
             if (p_has) {
-                const double ex = fmax(fmax(R.bx0 - p0, p0 - R.bx1), 0.0), ey = fmax(fmax(R.by0 - p1, p1 - R.by1), 0.0), ez = fmax(fmax(R.bz0 - p2, p2 - R.bz1), 0.0);
-                in = ex * ex + ey * ey + ez * ez <= rmax2;
+                const double nx = fmax(fmax(R.bx0 - p0, p0 - R.bx1), 0.0), ny = fmax(fmax(R.by0 - p1, p1 - R.by1), 0.0), nz = fmax(fmax(R.bz0 - p2, p2 - R.bz1), 0.0);
+                const double dmin2 = nx * nx + ny * ny + nz * nz;
+                in = dmin2 <= rmax2;
+                if (DEP_H == 1 && in) {
+                    const double fx_ = fmax(p0 - R.bx0, R.bx1 - p0), fy_ = fmax(p1 - R.by0, R.by1 - p1), fz_ = fmax(p2 - R.bz0, R.bz1 - p2);
+                    const double dmax2 = (fx_ * fx_ + fy_ * fy_ + fz_ * fz_) * (1.0 + 1e-12);
+                    const double nd = nbar.x * p3 + nbar.y * p4 + nbar.z * p5;                    // a hitpoint's n.g lies within ndev of it
+                    const double sc = fabs(p3 * (bcx - p0) + p4 * (bcy - p1) + p5 * (bcz - p2));  // |g.(h - q)| lies within `spread` of it
+                    const double spread = fabs(p3) * bex + fabs(p4) * bey + fabs(p5) * bez;
+                    const double f_hi = (sc + spread) * (1.0 + 1e-9), f_lo = fmax(sc - spread, 0.0) * (1.0 - 1e-9);
+                    const bool rej = nd + ndev < 1e-3 - 1e-9 || f_lo * f_lo > thr2_hi * dmax2 * (1.0 + 1e-9);
+                    easy = !rej && nd - ndev > 1e-3 + 1e-9 && dmin2 > 0.0 && f_hi * f_hi < thr2_lo * dmin2 * (1.0 - 1e-9);
+                    in = !rej;
+                }
             }
-            const unsigned long long m = ballot64(in);
+            const unsigned long long m_e = ballot64(in && easy), m_f = ballot64(in && !easy);
             if (in) {
-                double* row = s_row[wv][sel_n + __popcll(m & lt_mask)];
+                double* row = s_row[wv][easy ? __popcll(m_e & lt_mask) : DEP_ROWS - 1 - __popcll(m_f & lt_mask)];
                 row[0] = p0; row[1] = p1; row[2] = p2; row[3] = p3; row[4] = p4; row[5] = p5;
                 row[6] = __longlong_as_double(fx_fix(p6, fx_scale, clamped));
                 row[7] = __longlong_as_double(fx_fix(p7, fx_scale, clamped));
                 row[8] = __longlong_as_double(fx_fix(p8, fx_scale, clamped));
                 if (TAP) row[ROW - 1] = __longlong_as_double((long long)p_key);
             }
-            sel_n += __popcll(m);
+            n_easy = __popcll(m_e); n_full = __popcll(m_f);
+            sel_n = n_easy + n_full;
+            if (STAMPS) { d_easy += (unsigned long long)n_easy; d_full += (unsigned long long)n_full; }
             const unsigned long long t1 = DSTAMP();
             DEP_ISSUE()
             if (STAMPS) { st_append += t1 - t0; st_issue += DSTAMP() - t1; }
             if (sel_n == 0) continue;
         }
         const unsigned long long tp0 = DSTAMP();
-        // every hitpoint against the sel_n staged records: the search filter of src/kdtree.h:123-127 (its |cos| does
-        // not depend on the orientation of the normal) and the acceptance test of src/stochastic_ppm.h:441-445
+        // every hitpoint against the staged records: the search filter of src/kdtree.h:123-127 (its |cos| does not
+        // depend on the orientation of the normal) and the acceptance test of src/stochastic_ppm.h:441-445
         __builtin_amdgcn_wave_barrier();
         c_sel += (unsigned int)sel_n; c_pairs += (unsigned long long)sel_n * R.n_inc; c_round++;
-        const int sel_u = __builtin_amdgcn_readfirstlane(sel_n);
-        for (int ti = 0; ti < sel_u; ti++) {
+        const int ne_u = __builtin_amdgcn_readfirstlane(n_easy), nf_u = __builtin_amdgcn_readfirstlane(n_full);
+        // rows [0, n_easy): the normal and flatness tests pass for the whole cluster, the distance test alone decides;
+        // two records per trip (independent chains of LDS read -> subtract -> square -> compare)
+        for (int ti = 0; ti < ne_u; ti += 2) {
+            const bool two = ti + 1 < ne_u;
+            const double* row0 = s_row[wv][ti];
+            const double* row1 = s_row[wv][two ? ti + 1 : ti];
+            const d3 dir0 = mk(t.x[0], t.y[0], t.z[0]) - mk(row0[0], row0[1], row0[2]);
+            const d3 dir1 = mk(t.x[0], t.y[0], t.z[0]) - mk(row1[0], row1[1], row1[2]);
+            const double d2f0 = fma(dir0.z, dir0.z, fma(dir0.y, dir0.y, dir0.x * dir0.x));
+            const double d2f1 = fma(dir1.z, dir1.z, fma(dir1.y, dir1.y, dir1.x * dir1.x));
+            bool ok0 = d2f0 < lim_lo[0], ok1 = two && d2f1 < lim_lo[0];
+            // (lim_hi is -1 for a lane outside the cluster: never too close to call)
+            const bool unsure = (!ok0 && !(d2f0 > lim_hi[0])) || (two && !ok1 && !(d2f1 > lim_hi[0]));
+            if (ballot64(unsure) != 0ull) {
+                const double e0 = len2(dir0), e1 = len2(dir1);
+                ok0 = inc[0] && (e0 < tp.gather_r2) && (e0 <= t.r2[0]);
+                ok1 = two && inc[0] && (e1 < tp.gather_r2) && (e1 <= t.r2[0]);
+            }
+            if (ok0) {
+                ax[0] += __double_as_longlong(row0[6]); ay[0] += __double_as_longlong(row0[7]); az[0] += __double_as_longlong(row0[8]); am[0]++;
+                if (TAP) {
+                    const unsigned long long ts = atomicAdd(tp.tap_n, 1ull);
+                    if ((int64_t)ts < tp.tap_cap) { tp.tap_key[ts] = (unsigned long long)__double_as_longlong(row0[ROW - 1]); tp.tap_pix[ts] = t.p[0]; }
+                }
+            }
+            if (ok1) {
+                ax[0] += __double_as_longlong(row1[6]); ay[0] += __double_as_longlong(row1[7]); az[0] += __double_as_longlong(row1[8]); am[0]++;
+                if (TAP) {
+                    const unsigned long long ts = atomicAdd(tp.tap_n, 1ull);
+                    if ((int64_t)ts < tp.tap_cap) { tp.tap_key[ts] = (unsigned long long)__double_as_longlong(row1[ROW - 1]); tp.tap_pix[ts] = t.p[0]; }
+                }
+            }
+        }
+        // rows [64 - n_full, 64): the full test
+        for (int ti = DEP_ROWS - nf_u; ti < DEP_ROWS; ti++) {
             const double* row = s_row[wv][ti];
             const d3 g0 = mk(row[3], row[4], row[5]);
             const d3 qq = mk(row[0], row[1], row[2]);
@@ -429,6 +497,7 @@ __global__ void __launch_bounds__(256) DEP_ATTR k_deposit_tiles(HpArrays hp, Rec
         if (c_sel) atomicAdd(&counters[5], (unsigned long long)c_sel);
         if (c_round) atomicAdd(&counters[6], (unsigned long long)c_round);
         atomicAdd(&counters[7], 1ull);
+        if (STAMPS) { atomicAdd(&counters[22], d_easy); atomicAdd(&counters[23], d_rej); atomicAdd(&counters[15], d_full); }
     }
     __builtin_amdgcn_wave_barrier();
     st_flush += DSTAMP() - tf0;

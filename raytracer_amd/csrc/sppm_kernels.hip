@@ -1525,7 +1525,7 @@ static int deposit_tiles(sppm_ctx* c)
     if (c->timing) { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventRecord(e0, st)); }
     const bool stamps = getenv("SPPM_STAMPS") != nullptr;
     if (stamps) {
-        HIPCHK(hipMemsetAsync(c->d_counters + 16, 0, 6 * sizeof(unsigned long long), st));
+        HIPCHK(hipMemsetAsync(c->d_counters + 15, 0, 9 * sizeof(unsigned long long), st));
         hipLaunchKernelGGL((k_deposit_tiles<false, true>), dim3(blocks), dim3(256), 0, st, c->hp, BS.rec_s, BS.cell_start, tp, c->fx_scale, c->d_items, c->d_item_q, c->d_counters, c->d_err);
         unsigned long long t[24];
         HIPCHK(hipMemcpyAsync(t, c->d_counters, sizeof t, hipMemcpyDeviceToHost, st));
@@ -1533,6 +1533,7 @@ static int deposit_tiles(sppm_ctx* c)
         const double tot = (double)(t[16] + t[17] + t[18] + t[19] + t[20] + t[21]);
         fprintf(stderr, "[sppm] deposit: items %llu, shares of wave cycles: setup %.1f%% count %.1f%% issue %.1f%% append(wait) %.1f%% process %.1f%% flush %.1f%%; grid %dx%dx%d\n", t[7],
                 100.0 * t[16] / tot, 100.0 * t[17] / tot, 100.0 * t[18] / tot, 100.0 * t[19] / tot, 100.0 * t[20] / tot, 100.0 * t[21] / tot, g.nx, g.ny, g.nz);
+        fprintf(stderr, "[sppm]   staged records by class: distance test only %llu, rejected for the whole cluster %llu, full test %llu\n", t[22], t[23], t[15]);
     } else if (c->tap_cap > 0)
         hipLaunchKernelGGL(k_deposit_tiles<true>, dim3(blocks), dim3(256), 0, st, c->hp, BS.rec_s, BS.cell_start, tp, c->fx_scale, c->d_items, c->d_item_q, c->d_counters, c->d_err);
     else

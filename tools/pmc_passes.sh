@@ -13,7 +13,7 @@ for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_
            "SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_INT32 SQ_THREAD_CYCLES_VALU SQ_BUSY_CU_CYCLES SQ_CYCLES" \
            "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  timeout -s KILL 150 rocprofv3 --pmc $grp -d $O/p$i -o p -- python3 $R/bench.py --no-cpu-baseline "$@" > $O/bench_p$i.json 2>$O/p$i.err
+  timeout -s KILL 150 rocprofv3 --pmc $grp -d $O/p$i -o p -- python3 $R/bench.py --no-cpu-baseline --no-k-cap "$@" > $O/bench_p$i.json 2>$O/p$i.err
   echo "pass $i done"
 done
 cd $R
