@@ -1,23 +1,29 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the SPPM hot path on MI355X (contract: see the task statement).
 
-A "step" is one SPPM pass at BASELINE config 2 geometry (Cornell box, 1920x1080, samples =
-supersamples = 1, alpha 0.7, initial r^2 = 25 = search r^2): eye pass over every pixel, 1M photons
-per GPU traced and applied to the hitpoints with the reference's per-photon update, image resolve.
-The timed region is a FRESH render: passes 0..K-1 (default K = 256, the whole of config 2: "1M
-photons/pass x 256 passes on one MI355X"); the W warmup passes run before it on a scratch context of
-the same size (clocks, first touch), so they are not part of the render.  Pass cost falls as the
-radii shrink (pass 0 is ~10x a late pass), so K matters and is reported in config.workload.
-Nothing is uploaded inside the timed region (scene and state are resident in HBM).
+A "step" is one SPPM pass at BASELINE config 2 geometry (Cornell box, 1920x1080, samples = supersamples = 1,
+alpha 0.7, initial r^2 = 25 = search r^2): eye pass over every pixel, 1M photons per GPU traced and applied to the
+hitpoints, the progressive update, image resolve.  The timed region is a FRESH render: passes 0..K-1 (default
+K = 256, the whole of config 2: "1M photons/pass x 256 passes on one MI355X"); the W warmup passes run before it on a
+scratch context of the same size (clocks, first touch), so they are not part of the render.  Pass cost falls as the
+radii shrink (pass 0 is ~2.5x a late pass), so K matters and is reported in config.workload.  Nothing is uploaded
+inside the timed region (scene and state are resident in HBM).
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus 1 --steps K --warmup W [--rule {1,0}]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-N > 1 (weak scaling, config 3): a pass has N x photons photons; every rank owns a compact region of the
-hitpoints (a range of their Morton order), traces its block of every batch and receives the other ranks'
-photon-hit records through one RCCL all-gather per batch; photon paths are keyed by global photon index
-and every hitpoint replays its records in key order, so the result does not depend on N (tested with two
-ranks against one GPU, bit for bit).
+--rule picks the update rule of the primary line:
+  1 (default)  the per-pass (N, tau) update of src/stochastic_ppm.h:721-741 -- north_star's formulation.  N > 1: every
+               rank keeps all hitpoints, traces photons [rank M, (rank+1) M) of a pass of N x M, deposits them in 64-bit
+               fixed point, ONE all-reduce of 32 bytes per hitpoint per pass; bit-identical for every N.
+  0            the reference's live per-photon update (src/sppm2.h:391-421), ordered replay, exact for every N.  N > 1:
+               hitpoints partitioned by ranges of their Morton order, photon-hit records sorted by destination and
+               exchanged with one all-to-all per batch.
+At N = 1 the other rule is measured in the same run and reported beside the primary line (--one-rule skips it), with
+the relative RMSE between the two images; `k_cap` reports two passes with the reference's K = 10000 cap enforced
+exactly (the timed renders search uncapped: config.gather_max); `cpu_baseline` times the oracle's all-core photon pass
+on a bounded sample.  `roofline` is the gather kernel of the primary rule: algorithmic FP64 operations over HIP-event
+kernel time against the vector FP64 peak, with the committed rocprofv3 --pmc counters (profiles/r02_pmc_rule<R>.json).
 """
 import argparse
 import json
@@ -354,18 +360,23 @@ def report(args, world, rule, r, table_name):
             # the byte accounting of SURVEY 8(d), kept beside the bound that the counters show
             "alg_bytes_per_launch": alg_bytes / g_launch, "alg_GBps": alg_bytes / max(g_ns, 1),
             "update_bytes_GBps_at_60B": 60.0 * upd0 / max(g_ns, 1), "update_bytes_frac_of_hbm_peak": 60.0 * upd0 / max(g_ns, 1) / 8000.0,
-            "note": "rank 0; bound = VALU issue: the committed SQ counters (profiles/r02_pmc_rule%d.json) show the kernel's SIMDs issuing vector "
-                    "instructions %s of the time with HBM at a few percent of 8 TB/s, so the roofline is the FP64 vector peak; achieved = 23 flop x "
-                    "(record, hitpoint) pairs tested%s / kernel time from HIP events on the kernel's stream; peak 78.6 TFLOP/s counts every operation as an "
-                    "FMA -- the tests run with contraction off (bit-exact parity), where the attainable rate is 39.3 T operations/s; traffic = HBM bytes per "
-                    "launch from rocprofv3 --pmc (2 x FETCH_SIZE + WRITE_SIZE) of %s" % (
+            "note": "rank 0; bound = the vector ALU: the committed SQ counters (profiles/r02_pmc_rule%d.json) show it as the busiest unit of the kernel (VALU busy %s "
+                    "of the time every SIMD is occupied, LDS %s, HBM a few percent of 8 TB/s), so the roofline is the FP64 vector peak; the kernel does not "
+                    "saturate the pipe -- four wavefronts of 128 registers per SIMD leave dependent instructions and LDS round trips exposed.  achieved = 23 flop x "
+                    "(record, hitpoint) pairs examined%s / kernel time from HIP events on the kernel's stream: ALGORITHMIC operations (the reference's test of a "
+                    "pair); the kernels execute fewer%s.  peak 78.6 TFLOP/s counts every operation as an FMA -- the tests run with contraction off "
+                    "(bit-exact parity), where the attainable rate is 39.3 T operations/s; traffic = HBM bytes per launch from rocprofv3 --pmc "
+                    "(2 x FETCH_SIZE + WRITE_SIZE) of %s" % (
                         rule, ("%.0f %%" % (100.0 * pm["valu_active_share"])) if pm and pm.get("valu_active_share") else "most",
-                        " + 24 flop x accepted updates" if rule == 0 else "", pm.get("run", "the committed run") if pm else "(no committed counters for this workload)"),
+                        ("%.0f %%" % (100.0 * pm["lds_active_share"])) if pm and pm.get("lds_active_share") else "less",
+                        " + 24 flop x accepted updates" if rule == 0 else "",
+                        " (rule 1 decides the normal and flatness tests of ~80 % of the staged records once per cluster of 64 hitpoints and runs the 8-flop distance test alone on them)" if rule == 1 else "",
+                        pm.get("run", "the committed run") if pm else "(no committed counters for this workload)"),
         },
     }
     if pm:
         out["roofline"]["traffic_GBps"] = pm["hbm_bytes_per_launch"] / (pm.get("avg_launch_ms", g_ns / 1e6 / g_launch) * 1e6)
-        out["roofline"]["sq"] = {k: pm[k] for k in ("valu_active_share", "lds_active_share", "valu_insts_per_launch", "lds_bank_conflict_share") if k in pm}
+        out["roofline"]["sq"] = {k: pm[k] for k in ("valu_active_share", "lds_active_share", "wait_inst_any_share", "valu_insts_per_launch", "lds_bank_conflict_share") if k in pm}
     t_ns = c1["trace_ns"] - c0["trace_ns"]
     t_launch = max(1, c1["trace_launches"] - c0["trace_launches"])
     p_rays = c1["photon_rays"] - c0["photon_rays"]

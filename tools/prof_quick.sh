@@ -6,7 +6,7 @@ TAG=$1; shift
 O=$R/gpurun_out/prof_$TAG
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 280 rocprofv3 --kernel-trace --stats -d $O/st -o run -- python3 $R/bench.py --no-cpu-baseline "$@" > $O/bench.json 2>$O/prof.err
+timeout -k 10 280 rocprofv3 --kernel-trace --stats -d $O/st -o run -- python3 $R/bench.py --no-cpu-baseline --no-k-cap "$@" > $O/bench.json 2>$O/prof.err
 cd $R
 python tools/rocpd_summary.py stats $(find $O/st -name 'run_results.db') $O/kernel_stats.csv
 python tools/timeline_db.py $(find $O/st -name "run_results.db") 5 5 > $O/timeline.txt 2>&1 || true

@@ -1,7 +1,8 @@
 #!/bin/bash
-# scratch: bench the current library at the two step counts
-timeout -k 10 120 python bench.py --steps 20 --warmup 5 --one-rule --no-cpu-baseline --no-k-cap > gpurun_out/b20.json 2>gpurun_out/b20.err || exit 1
-timeout -k 10 200 python bench.py --steps 256 --warmup 2 --one-rule --no-cpu-baseline --no-k-cap > gpurun_out/b256.json 2>gpurun_out/b256.err || exit 1
+# scratch: bench the current library at the two step counts, one rule ($1, default 1)
+R=${1:-1}
+timeout -k 10 150 python bench.py --rule $R --steps 20 --warmup 5 --one-rule --no-cpu-baseline --no-k-cap > gpurun_out/b20.json 2>gpurun_out/b20.err || exit 1
+timeout -k 10 250 python bench.py --rule $R --steps 256 --warmup 2 --one-rule --no-cpu-baseline --no-k-cap > gpurun_out/b256.json 2>gpurun_out/b256.err || exit 1
 python3 - <<'PY'
 import json
 for f in ("b20", "b256"):
