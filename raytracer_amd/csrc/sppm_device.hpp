@@ -96,6 +96,30 @@ __device__ __forceinline__ XorShift make_stream(uint32_t base, uint64_t key)
 // ---- scene ----------------------------------------------------------------------------------
 struct Hit { double distance; d3 position, normal; int object_id; };
 
+// ---- wave-level helpers: a lane's double to all lanes, min / max over the wavefront
+__device__ __forceinline__ double rl_d(double v, int lane)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double first_d(double v)
+{
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+    const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_max_d(double v)
+{
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off));
+    return first_d(v);
+}
+__device__ __forceinline__ double wave_min_d(double v)
+{
+    for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off));
+    return first_d(v);
+}
+
 // edupt::intersect_scene, src/scene.h:53-76, over Sphere::intersect, src/sphere.h:31-56.
 // The kernels stage the sphere table in LDS first (STAGE_SCENE), so the per-sphere fields are LDS
 // broadcasts, and the body is branch-free so that the independent per-sphere chains (the square root

@@ -42,28 +42,7 @@ struct TileParams {
     unsigned long long* item_times;  // diagnostic (SPPM_ITEM_TIMES): start/end clock of every work item
 };
 
-__device__ __forceinline__ double rl_d(double v, int lane)
-{
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double first_d(double v)
-{
-    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
-    const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double wave_max_d(double v)
-{
-    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off));
-    return first_d(v);
-}
-__device__ __forceinline__ double wave_min_d(double v)
-{
-    for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off));
-    return first_d(v);
-}
+// (rl_d, first_d, wave_min_d, wave_max_d: sppm_device.hpp)
 // grid coordinate of x, clamped to [0, n-1]; monotone in x, so an interval maps to an index range
 __device__ __forceinline__ int grid_coord(double x, double o, double inv_c, int n)
 {

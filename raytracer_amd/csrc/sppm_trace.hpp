@@ -54,6 +54,9 @@ __device__ __forceinline__ void photon_emit(const DevScene& sc, const TraceParam
 }
 
 // one iteration of the while loop of create_photon; returns false when the path ends
+template <class RNG>
+__device__ __forceinline__ bool photon_shade(const DevScene& sc, PhotonState<RNG>& ps, const Hit& is, Deposit& dep, int32_t* __restrict__ err, const bool ppm);
+
 template <class RNG, int GRID>
 __device__ __forceinline__ bool photon_bounce(const DevScene& sc, PhotonState<RNG>& ps, Deposit& dep, int32_t* __restrict__ err, uint32_t& rays, const bool ppm)
 {
@@ -62,6 +65,13 @@ __device__ __forceinline__ bool photon_bounce(const DevScene& sc, PhotonState<RN
     Hit is;
     rays++;
     if (!intersect_scene<GRID>(sc, ps.org, ps.dir, is)) return false;
+    return photon_shade(sc, ps, is, dep, err, ppm);
+}
+
+// what create_photon does with a hit (src/sppm2.h:339-525): the record of a diffuse hit, roulette, the next direction
+template <class RNG>
+__device__ __forceinline__ bool photon_shade(const DevScene& sc, PhotonState<RNG>& ps, const Hit& is, Deposit& dep, int32_t* __restrict__ err, const bool ppm)
+{
     const sppm_sphere* obj = &sc.sp[is.object_id];
     const d3 color = ld3(obj->color);
     const int type = obj->reflection_type;
@@ -102,6 +112,9 @@ template <int MODE> struct TraceRng { typedef StreamRng type; };
 template <> struct TraceRng<0> { typedef XorShift type; };
 
 #define TRACE_GRAB 64
+#ifndef TRACE_COOP_MAX
+#define TRACE_COOP_MAX 6  // lanes still active below which the wavefront shares each lane's closest-hit search
+#endif
 #define REC_CHUNK 128  // record slots a wavefront reserves at a time (one atomic per chunk instead of one per record)
 #define REC_INVALID (~0ull)
 template <int MODE, int GRID>
@@ -140,6 +153,59 @@ __global__ void __launch_bounds__(256) k_photon_trace(DevScene sc, TraceParams t
         if (__ballot(active) == 0) { if (exhausted) break; else continue; }
         Deposit dep;
         dep.want = false;
+        // The tail of a launch: the photons are handed out and a few lanes still follow paths of thousands of bounces
+        // (total reflection inside the glass sphere), one lane's arithmetic per instruction.  Then the wavefront shares
+        // a lane's closest-hit search: the ray is broadcast, lane i tests sphere i (the arithmetic of intersect_scene's
+        // loop body), the smallest t wins and among equal t the lowest index -- the loop's strict `<` in index order.
+        const unsigned long long am = __ballot(active);
+        if (GRID == 0 && exhausted && __popcll(am) <= TRACE_COOP_MAX) {
+            const bool go = active && !ps.rng.stop() && !(max3(ps.flux) <= 0.0);
+            double my_best = SPPM_INF;
+            int my_id = -1;
+            for (unsigned long long mm = __ballot(go); mm != 0ull; mm &= mm - 1ull) {
+                const int a = __ffsll((long long)mm) - 1;
+                const d3 org = mk(rl_d(ps.org.x, a), rl_d(ps.org.y, a), rl_d(ps.org.z, a));
+                const d3 dir = mk(rl_d(ps.dir.x, a), rl_d(ps.dir.y, a), rl_d(ps.dir.z, a));
+                double best = SPPM_INF;
+                int id = -1;
+                for (int base = 0; base < sc.ns; base += 64) {
+                    const int i = base + lane;
+                    double t = SPPM_INF;
+                    if (i < sc.ns) {
+                        const d3 p_o = ld3(sc.sp[i].position) - org;
+                        const double b = dot(p_o, dir);
+                        const double D4 = b * b - dot(p_o, p_o) + sc.sp[i].radius * sc.sp[i].radius;
+                        const double sq = sqrt(D4);
+                        const double t1 = b - sq, t2 = b + sq;
+                        const bool counts = !(D4 < 0.0) && !(t1 < SPPM_EPS && t2 < SPPM_EPS);
+                        const double tt = (t1 > SPPM_EPS) ? t1 : t2;
+                        if (counts && tt < SPPM_INF) t = tt;
+                    }
+                    const double m = wave_min_d(t);
+                    if (m < best) { best = m; id = base + __ffsll((long long)__ballot(t == m)) - 1; }
+                }
+                if (lane == a) { my_best = best; my_id = id; }
+            }
+            // every lane then goes on with its own hit, in parallel
+            if (active) {
+                if (!go) active = false;
+                else {
+                    rays++;
+                    if (my_id < 0) active = false;
+                    else {
+                        Hit is;
+                        is.distance = my_best; is.object_id = my_id;
+                        is.position = ps.org + ps.dir * my_best;
+                        is.normal = normalize(is.position - ld3(sc.sp[my_id].position));
+                        active = photon_shade(sc, ps, is, dep, err, tp.ppm != 0);
+                    }
+                }
+                if constexpr (MODE == 2)
+                    if (!active) tp.consumed[ps.index] = ps.rng.stop() ? STREAM_OVER : (uint32_t)(ps.rng.pos - ps.index);
+                if constexpr (MODE == 1)
+                    if (!active && ps.rng.stop()) err[4] = 1;
+            }
+        } else
         if (active) {
             active = photon_bounce<RNG, GRID>(sc, ps, dep, err, rays, tp.ppm != 0);
             if constexpr (MODE == 2)
