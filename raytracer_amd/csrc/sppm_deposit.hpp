@@ -281,7 +281,7 @@ __global__ void __launch_bounds__(256) DEP_ATTR k_deposit_tiles(HpArrays hp, Rec
     st_count += DSTAMP() - ts_setup;
     unsigned int c_sel = 0, c_round = 0;
     unsigned long long c_pairs = 0;
-    unsigned long long d_easy = 0, d_rej = 0, d_full = 0; (void)d_rej;  // diagnostic build: staged records by class
+    unsigned long long d_easy = 0, d_full = 0;  // diagnostic build: staged records by class
     bool clamped = false;
     int sel_n = 0, n_easy = 0, n_full = 0;
     // iterator over the list in groups of 64 entries
@@ -497,7 +497,7 @@ __global__ void __launch_bounds__(256) DEP_ATTR k_deposit_tiles(HpArrays hp, Rec
         if (c_sel) atomicAdd(&counters[5], (unsigned long long)c_sel);
         if (c_round) atomicAdd(&counters[6], (unsigned long long)c_round);
         atomicAdd(&counters[7], 1ull);
-        if (STAMPS) { atomicAdd(&counters[22], d_easy); atomicAdd(&counters[23], d_rej); atomicAdd(&counters[15], d_full); }
+        if (STAMPS) { atomicAdd(&counters[22], d_easy); atomicAdd(&counters[15], d_full); }
     }
     __builtin_amdgcn_wave_barrier();
     st_flush += DSTAMP() - tf0;

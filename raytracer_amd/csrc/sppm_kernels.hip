@@ -1533,7 +1533,7 @@ static int deposit_tiles(sppm_ctx* c)
         const double tot = (double)(t[16] + t[17] + t[18] + t[19] + t[20] + t[21]);
         fprintf(stderr, "[sppm] deposit: items %llu, shares of wave cycles: setup %.1f%% count %.1f%% issue %.1f%% append(wait) %.1f%% process %.1f%% flush %.1f%%; grid %dx%dx%d\n", t[7],
                 100.0 * t[16] / tot, 100.0 * t[17] / tot, 100.0 * t[18] / tot, 100.0 * t[19] / tot, 100.0 * t[20] / tot, 100.0 * t[21] / tot, g.nx, g.ny, g.nz);
-        fprintf(stderr, "[sppm]   staged records by class: distance test only %llu, rejected for the whole cluster %llu, full test %llu\n", t[22], t[23], t[15]);
+        fprintf(stderr, "[sppm]   staged records by class: distance test only %llu, full test %llu (records rejected for the whole cluster are not staged)\n", t[22], t[15]);
     } else if (c->tap_cap > 0)
         hipLaunchKernelGGL(k_deposit_tiles<true>, dim3(blocks), dim3(256), 0, st, c->hp, BS.rec_s, BS.cell_start, tp, c->fx_scale, c->d_items, c->d_item_q, c->d_counters, c->d_err);
     else
