@@ -1353,11 +1353,15 @@ static int bin_into(sppm_ctx* c, int b, const TileGrid& g, hipStream_t st, bool 
     const uint32_t n_padded = (n_table + SCAN_BLOCK - 1) / SCAN_BLOCK * SCAN_BLOCK;
     // B.cell_cnt is all zero here: allocated so, and every scan clears what it has read (k_scan_add)
     // drop_far: only where the current view's occupancy map is final on this stream (not for batches binned ahead)
-    hipLaunchKernelGGL(k_bin_count, dim3(2048), dim3(256), 0, st, c->rec_buf[b], c->d_rec_count_buf[b], g, B.cell_cnt, B.rec_bucket, c->d_err,
+    // (binning ahead of its gather, on a tracer stream, has batches of slack: a narrow grid leaves the window between
+    // two gathers to the kernels the next gather waits for)
+    static const int bin_blocks_ahead = (int)env_i64("SPPM_BIN_BLOCKS", 256);
+    const int bin_blocks = st == c->stream ? 2048 : bin_blocks_ahead;
+    hipLaunchKernelGGL(k_bin_count, dim3(bin_blocks), dim3(256), 0, st, c->rec_buf[b], c->d_rec_count_buf[b], g, B.cell_cnt, B.rec_bucket, c->d_err,
                        near_map(c, drop_far));
     int rc = run_scan(c, B, n_padded, st, c->d_counters + 2);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_grid_scatter, dim3(2048), dim3(256), 0, st, c->rec_buf[b], B.rec_s, c->d_rec_count_buf[b], B.rec_bucket, B.cursor);
+    hipLaunchKernelGGL(k_grid_scatter, dim3(bin_blocks), dim3(256), 0, st, c->rec_buf[b], B.rec_s, c->d_rec_count_buf[b], B.rec_bucket, B.cursor);
     HIPCHK(hipGetLastError());
     B.g = g; B.binned = 1;
     return 0;
