@@ -1419,7 +1419,7 @@ static int gather_tiles(sppm_ctx* c)
     c->est_valid = 1; c->est_range = range;
     // persistent wavefronts: 4 per SIMD on every CU (fewer if there are few tiles)
     const unsigned int n_items = (unsigned int)c->n_owned * 64u + 64u;  // capacity of the item list (diagnostics only)
-    const int gather_blocks = std::max(1, std::min(nblk(c->n_owned, 4), 256 * GATHER_WAVES));
+    const int gather_blocks = std::max(1, std::min(nblk(c->n_owned, 4), (int)env_i64("SPPM_GATHER_BLOCKS", 256 * GATHER_WAVES)));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (dbg) { HIPCHK(hipMemsetAsync(c->d_counters + 8, 0, 16 * sizeof(unsigned long long), st)); }
     if (c->timing || dbg) { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventRecord(e0, st)); }
@@ -1524,7 +1524,7 @@ static int deposit_tiles(sppm_ctx* c)
     hipLaunchKernelGGL(k_items_bases, dim3(1), dim3(64), 0, st, c->d_item_q, c->d_rec_count);
     hipLaunchKernelGGL(k_items_scatter, dim3(nblk(n_dep_tiles, 256)), dim3(256), 0, st, c->d_items_raw, c->d_n_pieces, n_dep_tiles, c->d_item_q, c->d_items);
     c->est_valid = 0;  // (the estimates of the ordered gather's plan are not made here)
-    const int blocks = std::max(1, std::min(nblk(n_dep_tiles, 4) * 4, (int)env_i64("SPPM_DEP_BLOCKS", 256 * (DEP_H == 1 ? 4 : 3))));
+    const int blocks = std::max(1, std::min(nblk(n_dep_tiles, 4) * 4, (int)env_i64("SPPM_DEP_BLOCKS", 256 * 3)));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->timing) { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventRecord(e0, st)); }
     const bool stamps = getenv("SPPM_STAMPS") != nullptr;
