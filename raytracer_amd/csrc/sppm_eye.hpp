@@ -223,8 +223,12 @@ __device__ __forceinline__ void eye_pixel(const DevScene& sc, const EyeParams& e
     eye_pixel_end<RNG, COMMIT>(ep, hp, out, e);
 }
 
+// Register budget of the eye pass: 128 per lane (four wavefronts per SIMD), although the kernel would like 168.  The next
+// pass's eye pass runs beside the gather, whose persistent wavefronts hold 3 x 128 registers of every SIMD: with 128 a
+// wavefront of the eye pass fits into what is left and the pass finishes in the gather's shadow; with 168 it waited
+// for the gather's tail (measured: +2 % on the pass).
 #ifndef EYE_WAVES
-#define EYE_WAVES 3
+#define EYE_WAVES 4
 #endif
 // One thread per pixel, one XorShift stream per (pass, image index).
 template <int GRID>

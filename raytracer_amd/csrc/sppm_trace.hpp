@@ -117,8 +117,16 @@ template <> struct TraceRng<0> { typedef XorShift type; };
 #endif
 #define REC_CHUNK 128  // record slots a wavefront reserves at a time (one atomic per chunk instead of one per record)
 #define REC_INVALID (~0ull)
+#ifndef TRACE_WAVES
+#define TRACE_WAVES 0  // 0: the compiler's choice (147 registers, three wavefronts per SIMD)
+#endif
+#if TRACE_WAVES > 0
+#define TRACE_ATTR __attribute__((amdgpu_waves_per_eu(TRACE_WAVES, TRACE_WAVES)))
+#else
+#define TRACE_ATTR
+#endif
 template <int MODE, int GRID>
-__global__ void __launch_bounds__(256) k_photon_trace(DevScene sc, TraceParams tp, RecArrays rec, unsigned long long* __restrict__ rec_count,
+__global__ void __launch_bounds__(256) TRACE_ATTR k_photon_trace(DevScene sc, TraceParams tp, RecArrays rec, unsigned long long* __restrict__ rec_count,
                                                       unsigned long long* __restrict__ next_block, unsigned long long* __restrict__ counters,
                                                       int32_t* __restrict__ err)
 {
