@@ -211,6 +211,14 @@ static int dev_alloc(sppm_ctx* c, T** p, size_t n, bool zero = true)
     return 0;
 }
 
+// The sort of the hitpoints' Morton keys runs beside the gather, whose persistent wavefronts leave one wavefront slot of
+// 128 registers per SIMD.  rocPRIM's tuned Onesweep kernel for (64-bit key, 32-bit value) uses workgroups of 512 threads,
+// two wavefronts per SIMD, which found no room until the gather's tail (one pass of it took 2.4 ms instead of 40 us).
+// The same algorithm (8 bits per pass, match-based ranking) with workgroups of 256 threads fits.
+typedef rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                   rocprim::radix_sort_onesweep_config<rocprim::kernel_config<256, 32>, rocprim::kernel_config<256, 12>, 8,
+                                                                       rocprim::block_radix_rank_algorithm::match>> HpSortConfig;
+
 static void host_normalize(const double* v, double* o)
 {
     const double inv = 1.0 / std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
@@ -559,7 +567,7 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
         c->split_factor = 4.0; c->est_per_photon = 0.0; c->est_range = 0;
         { const char* e = getenv("SPPM_SPLIT_FACTOR"); if (e && *e) c->split_factor = atof(e); }
         if (c->n_own_pix > 0) {
-            if (rocprim::radix_sort_pairs(nullptr, c->sort_tmp_bytes, c->d_hp_keys, c->d_hp_keys_out, c->d_own_pix, c->d_order,
+            if (rocprim::radix_sort_pairs<HpSortConfig>(nullptr, c->sort_tmp_bytes, c->d_hp_keys, c->d_hp_keys_out, c->d_own_pix, c->d_order,
                                           (size_t)c->n_own_pix, 0, 3 * MORTON_BITS + 1, c->stream) != hipSuccess) {
                 sppm_destroy(c); return fail(SPPM_ERR_HIP, "sizing the hitpoint sort failed");
             }
@@ -858,7 +866,7 @@ static int eye_launch(sppm_ctx* c, int32_t pass, hipStream_t st)
         hipLaunchKernelGGL(k_hp_bbox, dim3(std::min(nblk(c->n_own_pix, 256), 512)), dim3(256), 0, st, c->view[nv], c->d_own_pix, c->n_own_pix, c->d_hp_bb_r[slot]);
         hipLaunchKernelGGL(k_hp_sortkeys, dim3(nblk(c->n_own_pix, 256)), dim3(256), 0, st, c->view[nv], c->d_own_pix, c->n_own_pix, c->d_hp_bb_r[slot], c->d_hp_keys);
         HIPCHK(hipGetLastError());
-        HIPCHK(rocprim::radix_sort_pairs(c->d_sort_tmp, c->sort_tmp_bytes, c->d_hp_keys, c->d_hp_keys_out, c->d_own_pix, c->d_order_r[slot],
+        HIPCHK(rocprim::radix_sort_pairs<HpSortConfig>(c->d_sort_tmp, c->sort_tmp_bytes, c->d_hp_keys, c->d_hp_keys_out, c->d_own_pix, c->d_order_r[slot],
                                          (size_t)c->n_own_pix, 0, 3 * MORTON_BITS + 1, st));
         if (c->own_pending) {
             // Spatial ownership: this rank keeps positions [rank*P/N, (rank+1)*P/N) of the order just made
