@@ -31,6 +31,17 @@ def main():
         hp = job.ctx.hitpoints()
         np.savez(os.path.join(out_dir, "rank0.npz"), image=img.cpu().numpy(), n=hp["n"], r2=hp["r2"], flux=hp["flux"], mask=job.ctx.owned_mask().cpu().numpy())
         job.close()
+        # the ragged all-to-all of the exchange by destination and the int64 all-reduce of the per-pass rule, on RCCL
+        from raytracer_amd import parallel
+        src = torch.arange(70, dtype=torch.float64, device="cuda").reshape(7, 10)
+        dst = torch.empty((7, 10), dtype=torch.float64, device="cuda")
+        table = parallel.exchange_count_rows([7], 1, torch.device("cuda"))
+        parallel.all_to_all_rows([dst[:table[0][0]]], [src], 0)
+        dep = torch.arange(4 * 64, dtype=torch.int64, device="cuda").reshape(4, 64) + (1 << 40)
+        want = dep.clone()
+        parallel.all_reduce_sum(dep)
+        torch.cuda.synchronize()
+        assert table == [[7]] and torch.equal(dst, src) and torch.equal(dep, want)
         dist.destroy_process_group()
         return
     dist.init_process_group("gloo", rank=rank, world_size=world)

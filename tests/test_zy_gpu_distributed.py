@@ -118,7 +118,7 @@ def test_two_ranks_classic_ppm_equal_one_gpu(tmp_path):
             assert (a.view(np.uint64) == b.view(np.uint64)).all() if a.dtype.kind == "f" else (a == b).all(), k
 
 
-def test_allgather_flow_over_rccl_with_one_rank(tmp_path):
+def test_allgather_flow_over_rccl_with_one_rank(tmp_path):  # also: dist.all_to_all (ragged lists) and the int64 all-reduce on RCCL
     """The exchange of ShardedSppm on the real backend: a process group of ONE rank over RCCL (all a one-GPU box allows)
     runs the pipelined flow -- block traced ahead, packed rows, counts and records all-gathered on the side stream,
     append, gather, masked all-reduce of the image -- and must reproduce the plain single-GPU passes bit for bit."""
