@@ -220,6 +220,9 @@ int sppm_fixed_point_scale(sppm_ctx* ctx, double* scale);
 
 /* Image assembly, src/sppm2.h:658-670: d_image[P][3] = ld/(pass+1) + flux/(pi r^2 (pass+1) photon_num). */
 int sppm_resolve(sppm_ctx* ctx, int32_t pass, int64_t photon_num, double* d_image);
+/* sppm_end_pass then sppm_resolve in one call (src/stochastic_ppm.h:721-741 then :743-765; src/sppm2.h:658-670 under
+ * rule 0).  Under the per-pass rule both run as ONE sweep over the hitpoints; results are those of the two calls. */
+int sppm_end_pass_resolve(sppm_ctx* ctx, int32_t pass, int64_t photon_num, double* d_image);
 
 /* get_hdr_pixel on the device (src/hdr.h:37-45): d_rgbe[n][4]. */
 int sppm_hdr_pixels(sppm_ctx* ctx, const double* d_rgb, int64_t n, uint8_t* d_rgbe);

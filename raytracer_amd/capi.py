@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("SPPM_HIP_LIB") or os.path.join(_HERE, "libsppm_hip.so
 SYMBOLS = [
     "sppm_last_error", "sppm_device_count", "sppm_create", "sppm_destroy", "sppm_camera_rays", "sppm_intersect",
     "sppm_eye_pass", "sppm_photon_pass", "sppm_trace", "sppm_pack_records", "sppm_append_records", "sppm_gather",
-    "sppm_end_pass", "sppm_resolve", "sppm_hdr_pixels", "sppm_save_hdr_file", "sppm_save_ppm_file", "sppm_check",
+    "sppm_end_pass", "sppm_resolve", "sppm_end_pass_resolve", "sppm_hdr_pixels", "sppm_save_hdr_file", "sppm_save_ppm_file", "sppm_check",
     "sppm_download_hitpoints", "sppm_download_records", "sppm_owned_mask", "sppm_look_ahead", "sppm_look_ahead_rows", "sppm_rows_ready", "sppm_look_ahead_rows_to", "sppm_rows_ready_to", "sppm_download_tile_order", "sppm_accept_tap", "sppm_download_accepted", "sppm_counters",
     "sppm_set_timing", "sppm_measure_fma_peak", "sppm_intersect_static", "sppm_export_deposits", "sppm_import_deposits", "sppm_fixed_point_scale", "sppm_hitpoint_count", "sppm_download_hitpoint_pixels", "sppm_export_owned_state", "sppm_import_state",
 ]
@@ -63,6 +63,7 @@ def lib():
     L.sppm_gather.argtypes = [vp]
     L.sppm_end_pass.argtypes = [vp]
     L.sppm_resolve.argtypes = [vp, i32, i64, vp]
+    L.sppm_end_pass_resolve.argtypes = [vp, i32, i64, vp]
     L.sppm_hdr_pixels.argtypes = [vp, vp, i64, vp]
     L.sppm_save_hdr_file.argtypes = [C.c_char_p, vp, i32, i32]
     L.sppm_save_ppm_file.argtypes = [C.c_char_p, vp, i32, i32]

@@ -533,3 +533,37 @@ __global__ void k_end_pass(HpArrays hp, DevScene sc, Own own, double alpha, doub
     }
     hp.w[p] = 0.0; hp.w[P + p] = 0.0; hp.w[2 * P + p] = 0.0;
 }
+
+// k_end_pass and k_resolve (sppm_image.hpp) in one sweep over the hitpoints: the image reads what the update has just
+// computed from registers instead of from memory in a second launch.  Same operations, same results.
+__global__ void k_end_pass_resolve(HpArrays hp, DevScene sc, Own own, double alpha, double fx_inv, int32_t* __restrict__ err, int pass, int64_t photon_num,
+                                   double* __restrict__ image)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t P = (size_t)hp.P;
+    if (p >= hp.P) return;
+    d3 c = mk(hp.ld[p], hp.ld[P + p], hp.ld[2 * P + p]) / (double)(pass + 1);
+    if (hp.valid[p]) {
+        d3 tau = mk(hp.tau[p], hp.tau[P + p], hp.tau[2 * P + p]);
+        double r2 = hp.r2[p];
+        if (owned(own, p)) {
+            const long long madd = hp.dep[3 * P + p];
+            if (madd > 0) {
+                if (madd >= FX_MAX_DEPOSITS) err[6] = 1;
+                const double N = hp.nd[p];
+                const double Nnew = N + alpha * (double)madd;
+                const double Rnew2 = r2 * Nnew / (N + (double)madd);
+                const d3 phi = had(mk((double)hp.dep[p] * fx_inv, (double)hp.dep[P + p] * fx_inv, (double)hp.dep[2 * P + p] * fx_inv), ld3(sc.sp[hp.obj[p]].color) / SPPM_PI);
+                const d3 w = mk(hp.w[p], hp.w[P + p], hp.w[2 * P + p]);
+                tau = (tau + had(phi, w)) * Rnew2 / r2;
+                r2 = Rnew2;
+                hp.tau[p] = tau.x; hp.tau[P + p] = tau.y; hp.tau[2 * P + p] = tau.z;
+                hp.nd[p] = Nnew; hp.r2[p] = Rnew2;
+                hp.dep[p] = 0; hp.dep[P + p] = 0; hp.dep[2 * P + p] = 0; hp.dep[3 * P + p] = 0;
+            }
+            hp.w[p] = 0.0; hp.w[P + p] = 0.0; hp.w[2 * P + p] = 0.0;
+        }
+        c = c + tau * (1.0 / (SPPM_PI * r2 * (double)((int64_t)(pass + 1) * photon_num)));
+    }
+    image[3 * (size_t)p] = c.x; image[3 * (size_t)p + 1] = c.y; image[3 * (size_t)p + 2] = c.z;
+}

@@ -1847,6 +1847,21 @@ extern "C" int sppm_resolve(sppm_ctx* c, int32_t pass, int64_t photon_num, doubl
     return SPPM_OK;
 }
 
+// sppm_end_pass followed by sppm_resolve; under the per-pass rule both in ONE sweep over the hitpoints
+extern "C" int sppm_end_pass_resolve(sppm_ctx* c, int32_t pass, int64_t photon_num, double* d_image)
+{
+    if (!c || !d_image || pass < 0 || photon_num < 1) return fail(SPPM_ERR_INVALID, "sppm_end_pass_resolve: bad argument");
+    CTX_DEVICE(c, "sppm_end_pass_resolve");
+    if (c->cfg.update_rule != 1 || c->algo == 1 || c->P == 0) {
+        int rc = sppm_end_pass(c);
+        if (rc) return rc;
+        return sppm_resolve(c, pass, photon_num, d_image);
+    }
+    hipLaunchKernelGGL(k_end_pass_resolve, dim3(nblk(c->P, 256)), dim3(256), 0, c->stream, c->hp, scene_of(c), own_of(c), c->cfg.alpha, 1.0 / c->fx_scale, c->d_err, pass, photon_num, d_image);
+    HIPCHK(hipGetLastError());
+    return SPPM_OK;
+}
+
 extern "C" int sppm_hdr_pixels(sppm_ctx* c, const double* d_rgb, int64_t n, uint8_t* d_rgbe)
 {
     if (!c || n < 0 || (n > 0 && (!d_rgb || !d_rgbe))) return fail(SPPM_ERR_INVALID, "sppm_hdr_pixels: bad argument");

@@ -101,9 +101,10 @@ class ShardedSppm:
             ctx.photon_pass(i, self.M)
         else:
             self._photon_pass_allgather(i)
-        ctx.end_pass()
         if resolve:
-            self.image = ctx.resolve(i, self.M)
+            self.image = ctx.end_pass_resolve(i, self.M)
+        else:
+            ctx.end_pass()
         return self.image
 
     # ---- per-pass rule: one all-reduce of the deposits ---------------------------------------------------

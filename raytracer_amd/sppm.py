@@ -143,6 +143,12 @@ class SppmContext:
         capi.check(self.L.sppm_resolve(self.h, i, photon_num, img.data_ptr()))
         return img
 
+    def end_pass_resolve(self, i, photon_num):
+        """end_pass() then resolve(): under the per-pass rule one sweep over the hitpoints (sppm_end_pass_resolve)"""
+        img = self.torch.empty((self.P, 3), dtype=self.torch.float64, device=self.device)
+        capi.check(self.L.sppm_end_pass_resolve(self.h, i, photon_num, img.data_ptr()))
+        return img
+
     def hdr_pixels(self, rgb):
         t = self.torch
         rgb = rgb.to(device=self.device, dtype=t.float64).contiguous()

@@ -151,3 +151,20 @@ def test_per_pass_rule_1080p_properties():
     for k in ("n", "r2", "flux"):
         _same(sa[k], sb[k], k)
     a.check(); b.check(); a.close(); b.close()
+
+
+@pytest.mark.parametrize("rule", [1, 0])
+def test_fused_end_of_pass_equals_the_two_calls(rule):
+    """sppm_end_pass_resolve == sppm_end_pass + sppm_resolve: state and image bit for bit, pass after pass"""
+    W, H, M = 96, 64, 20000
+    a = sppm.SppmContext(sppm.make_config(W, H, photons_per_pass=M, update_rule=rule))
+    b = sppm.SppmContext(sppm.make_config(W, H, photons_per_pass=M, update_rule=rule))
+    for i in range(3):
+        a.eye_pass(i); a.photon_pass(i, M); a.end_pass(); ia = a.resolve(i, M).cpu().numpy()
+        b.eye_pass(i); b.photon_pass(i, M); ib = b.end_pass_resolve(i, M).cpu().numpy()
+        _same(ib, ia, f"pass {i} image")
+        sa, sb = a.hitpoints(), b.hitpoints()
+        for k in ("r2", "flux", "n"):
+            _same(sb[k], sa[k], f"pass {i} state {k}")
+    a.check(); b.check()
+    a.close(); b.close()
