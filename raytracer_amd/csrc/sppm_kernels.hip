@@ -395,7 +395,7 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
     c->slab_B = env_i64("SPPM_SLAB_PHOTONS", 1024);
     c->cell_factor_dep = 0.15;
     { const char* e = getenv("SPPM_DEP_CELL_FACTOR"); if (e && *e && atof(e) > 0.0) c->cell_factor_dep = atof(e); }
-    c->dep_chunk = std::max<int64_t>(64, env_i64("SPPM_DEP_CHUNK", 2048));
+    c->dep_chunk = std::max<int64_t>(64, env_i64("SPPM_DEP_CHUNK", 4096));
     c->rec_first = c->rec_end = 0;
     c->photons_applied = 0;
     c->ns = n_spheres;
