@@ -16,7 +16,7 @@
 // broadcast) and adds the record's pre-converted flux.  Several items add to the same hitpoint with integer atomics.
 #pragma once
 
-// (fx_fix, the fixed point of the deposits, is defined in sppm_gather_simple.hpp, which also uses it)
+// (fx_fix, the fixed point of the deposits, is applied by k_grid_scatter, sppm_records.hpp: the flux planes this kernel reads hold its bits)
 
 // A wavefront holds DEP_H hitpoints per lane: a tile of the deposit is 64 * DEP_H consecutive hitpoints of the
 // Morton order (lane l holds entries l, 64 + l, ...).  Every staged record is read from LDS once per wavefront
@@ -169,29 +169,33 @@ __global__ void __launch_bounds__(256) k_deposit_plan(HpArrays hp, const uint32_
     if (lane == 0) { est[k] = total; n_pieces[k] = (uint8_t)n_out; }
 }
 
+#ifndef DEP_EASY_TRIP
+#define DEP_EASY_TRIP 2  // records of the distance-only class per trip of their loop (independent chains of LDS read -> three fused multiply-adds -> compare)
+#endif
 #ifndef DEP_WAVES
 #define DEP_WAVES (DEP_H == 1 ? 4 : 3)  // register budget: 512 / DEP_WAVES per lane
 #endif
 #define DEP_ATTR __attribute__((amdgpu_waves_per_eu(DEP_WAVES, DEP_WAVES)))
 #define DEP_ROWS 64  // staged records per wavefront: one group of candidates at a time, processed while the next group's loads are in flight
 template <bool TAP, bool STAMPS = false>
-__global__ void __launch_bounds__(256) DEP_ATTR k_deposit_tiles(HpArrays hp, RecArrays rec, const uint32_t* __restrict__ cell_start, TileParams tp, double fx_scale,
+__global__ void __launch_bounds__(256) DEP_ATTR k_deposit_tiles(HpArrays hp, RecArrays rec, const uint32_t* __restrict__ cell_start, TileParams tp,
                                                        const uint32_t* __restrict__ items, unsigned int* __restrict__ q,
                                                        unsigned long long* __restrict__ counters, int32_t* __restrict__ err)
 {
-    constexpr int ROW = TAP ? 10 : 9;
-    __shared__ double s_row[4][DEP_ROWS][ROW];  // a staged record: position, geometric normal, fixed-point flux (3 x int64 bits)[, key bits]
+    constexpr int ROW = TAP ? 11 : 10;
+    // a staged record of the full test: position, geometric normal, fixed-point flux (3 x int64 bits); of the distance-only
+    // test: position about the cluster's centre, its square, flux, position; [ROW - 1: key bits]
+    __shared__ double s_row[4][DEP_ROWS][ROW];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int P = hp.P;
     const double thr = tp.gather_r2 * 0.01;
     const double band_rel = 1e-9 + 8e-15 / thr;
     const double thr2_lo = thr * thr * (1.0 - band_rel), thr2_hi = thr * thr * (1.0 + band_rel);
-    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const int64_t cap = rec.cap;
     const unsigned int n_items = q[0];
     const unsigned int n_waves = gridDim.x * 4u;
 #define DSTAMP() (STAMPS ? (unsigned long long)__builtin_amdgcn_s_memtime() : 0ull)
-    unsigned long long st_setup = 0, st_count = 0, st_issue = 0, st_append = 0, st_process = 0, st_flush = 0;  // diagnostic build only
+    unsigned long long st_setup = 0, st_count = 0, st_issue = 0, st_append = 0, st_process = 0, st_flush = 0, st_wait = 0;  // diagnostic build only
     for (bool first_item = true;; first_item = false) {
     const unsigned long long ts_item = DSTAMP();
     // persistent wavefronts over the list of items, heaviest first (as k_gather_tiles)
@@ -220,7 +224,7 @@ __global__ void __launch_bounds__(256) DEP_ATTR k_deposit_tiles(HpArrays hp, Rec
     }
     const DepRegion R = dep_region(t, inc, tp);
     if (R.n_inc == 0) continue;
-    const double rmax2 = R.rmax * R.rmax;
+    const double rmax2 = pin_scalar_d(R.rmax * R.rmax);  // (pin_scalar_d: wave-uniform values kept in scalar registers, see the cluster bounds below)
     const int kx = R.cx1 - R.cx0 + 1, ky = R.cy1 - R.cy0 + 1, kz = R.cz1 - R.cz0 + 1;
     const int Ktot = kx * ky * kz;
     d3 hn[DEP_H];
@@ -271,18 +275,35 @@ __global__ void __launch_bounds__(256) DEP_ATTR k_deposit_tiles(HpArrays hp, Rec
     //   and two thirds of the LDS reads of the full test, which the rest of the records still take.
     double ndev = 0.0;
     d3 nbar = mk(0, 0, 0);
-    const double bcx = 0.5 * (R.bx0 + R.bx1), bcy = 0.5 * (R.by0 + R.by1), bcz = 0.5 * (R.bz0 + R.bz1);
-    const double bex = (0.5 * (R.bx1 - R.bx0)) * (1.0 + 1e-12) + 1e-12, bey = (0.5 * (R.by1 - R.by0)) * (1.0 + 1e-12) + 1e-12, bez = (0.5 * (R.bz1 - R.bz0)) * (1.0 + 1e-12) + 1e-12;
+    // (wave-uniform, but computed by vector instructions: without the pin they stay in vector registers, of which the
+    // kernel has none to spare -- three of them were spilled and re-read from scratch memory for every group staged)
+    const double bcx = pin_scalar_d(0.5 * (R.bx0 + R.bx1)), bcy = pin_scalar_d(0.5 * (R.by0 + R.by1)), bcz = pin_scalar_d(0.5 * (R.bz0 + R.bz1));
+    const double bex = pin_scalar_d((0.5 * (R.bx1 - R.bx0)) * (1.0 + 1e-12) + 1e-12), bey = pin_scalar_d((0.5 * (R.by1 - R.by0)) * (1.0 + 1e-12) + 1e-12),
+                 bez = pin_scalar_d((0.5 * (R.bz1 - R.bz0)) * (1.0 + 1e-12) + 1e-12);
     if (DEP_H == 1) {
         const int seed = __ffsll((long long)ballot64(inc[0])) - 1;
         nbar = mk(rl_d(hn[0].x, seed), rl_d(hn[0].y, seed), rl_d(hn[0].z, seed));
-        ndev = sqrt(wave_max_d(inc[0] ? len2(hn[0] - nbar) : 0.0)) * (1.0 + 1e-9) + 1e-15;
+        ndev = pin_scalar_d(sqrt(wave_max_d(inc[0] ? len2(hn[0] - nbar) : 0.0)) * (1.0 + 1e-9) + 1e-15);
+    }
+    // The distance test of the "easy" records, expanded about the cluster's centre c (h' = h - c, q' = q - c):
+    // |h - q|^2 - |h'|^2 = |q'|^2 - 2 h'.q', three fused multiply-adds per pair from the record's (q', |q'|^2) against
+    // per-lane constants, compared with lim - |h'|^2.  About the centre every term is of the size of the cluster plus
+    // the search radius, so the value differs from the reference's |h - q|^2 by at most ~40 roundings of (Hm + Qm)^2
+    // (Hm, Qm: the largest |h'|, |q'|); a comparison closer than E = 900 such roundings to its bound is not trusted and
+    // the record is evaluated again in the reference's operation order from the positions themselves.
+    const double hcx = t.x[0] - bcx, hcy = t.y[0] - bcy, hcz = t.z[0] - bcz;
+    const double m2x = -2.0 * hcx, m2y = -2.0 * hcy, m2z = -2.0 * hcz;
+    const double hh = fma(hcz, hcz, fma(hcy, hcy, hcx * hcx));
+    double lo_c = -INFINITY, hi_c = -INFINITY;  // a lane outside the cluster: never inside, never too close to call
+    if (DEP_H == 1) {
+        const double Hm = sqrt(wave_max_d(inc[0] ? hh : 0.0)), Qm = sqrt(bex * bex + bey * bey + bez * bez) + R.rmax;
+        const double E = 1e-13 * (Hm + Qm) * (Hm + Qm);
+        if (inc[0]) { lo_c = (lim_lo[0] - hh) - E; hi_c = (lim_hi[0] - hh) + E; }
     }
     st_count += DSTAMP() - ts_setup;
     unsigned int c_sel = 0, c_round = 0;
     unsigned long long c_pairs = 0;
     unsigned long long d_easy = 0, d_full = 0;  // diagnostic build: staged records by class
-    bool clamped = false;
     int sel_n = 0, n_easy = 0, n_full = 0;
     // iterator over the list in groups of 64 entries
     int qbase = -64;
@@ -340,6 +361,7 @@ __global__ void __launch_bounds__(256) DEP_ATTR k_deposit_tiles(HpArrays hp, Rec
     while (pend || sel_n > 0) {
         if (pend) {
             const unsigned long long t0 = DSTAMP();
+            if (STAMPS) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); st_wait += DSTAMP() - t0; }  // (how long the group's loads are waited for)
             // the pending group: keep what lies within rmax of the cluster's bounding box (a hitpoint of the cluster
             // can only accept such records), sort it by class (see above: dropped / distance test only / full test)
             // while each lane still holds its record in registers, compact it into the staging rows -- "easy" records
@@ -363,11 +385,16 @@ __global__ void __launch_bounds__(256) DEP_ATTR k_deposit_tiles(HpArrays hp, Rec
             }
             const unsigned long long m_e = ballot64(in && easy), m_f = ballot64(in && !easy);
             if (in) {
-                double* row = s_row[wv][easy ? __popcll(m_e & lt_mask) : DEP_ROWS - 1 - __popcll(m_f & lt_mask)];
-                row[0] = p0; row[1] = p1; row[2] = p2; row[3] = p3; row[4] = p4; row[5] = p5;
-                row[6] = __longlong_as_double(fx_fix(p6, fx_scale, clamped));
-                row[7] = __longlong_as_double(fx_fix(p7, fx_scale, clamped));
-                row[8] = __longlong_as_double(fx_fix(p8, fx_scale, clamped));
+                double* row = s_row[wv][easy ? (int)mbcnt64(m_e) : DEP_ROWS - 1 - (int)mbcnt64(m_f)];
+                const double f6 = p6, f7 = p7, f8 = p8;  // fixed-point bits already (k_grid_scatter)
+                if (easy) {
+                    const double qx = p0 - bcx, qy = p1 - bcy, qz = p2 - bcz;
+                    row[0] = qx; row[1] = qy; row[2] = qz; row[3] = fma(qz, qz, fma(qy, qy, qx * qx));
+                    row[4] = f6; row[5] = f7; row[6] = f8; row[7] = p0; row[8] = p1; row[9] = p2;
+                } else {
+                    row[0] = p0; row[1] = p1; row[2] = p2; row[3] = p3; row[4] = p4; row[5] = p5;
+                    row[6] = f6; row[7] = f7; row[8] = f8;
+                }
                 if (TAP) row[ROW - 1] = __longlong_as_double((long long)p_key);
             }
             n_easy = __popcll(m_e); n_full = __popcll(m_f);
@@ -386,34 +413,35 @@ __global__ void __launch_bounds__(256) DEP_ATTR k_deposit_tiles(HpArrays hp, Rec
         const int ne_u = __builtin_amdgcn_readfirstlane(n_easy), nf_u = __builtin_amdgcn_readfirstlane(n_full);
         // rows [0, n_easy): the normal and flatness tests pass for the whole cluster, the distance test alone decides;
         // two records per trip (independent chains of LDS read -> subtract -> square -> compare)
-        for (int ti = 0; ti < ne_u; ti += 2) {
-            const bool two = ti + 1 < ne_u;
-            const double* row0 = s_row[wv][ti];
-            const double* row1 = s_row[wv][two ? ti + 1 : ti];
-            const d3 dir0 = mk(t.x[0], t.y[0], t.z[0]) - mk(row0[0], row0[1], row0[2]);
-            const d3 dir1 = mk(t.x[0], t.y[0], t.z[0]) - mk(row1[0], row1[1], row1[2]);
-            const double d2f0 = fma(dir0.z, dir0.z, fma(dir0.y, dir0.y, dir0.x * dir0.x));
-            const double d2f1 = fma(dir1.z, dir1.z, fma(dir1.y, dir1.y, dir1.x * dir1.x));
-            bool ok0 = d2f0 < lim_lo[0], ok1 = two && d2f1 < lim_lo[0];
-            // (lim_hi is -1 for a lane outside the cluster: never too close to call)
-            const bool unsure = (!ok0 && !(d2f0 > lim_hi[0])) || (two && !ok1 && !(d2f1 > lim_hi[0]));
-            if (ballot64(unsure) != 0ull) {
-                const double e0 = len2(dir0), e1 = len2(dir1);
-                ok0 = inc[0] && (e0 < tp.gather_r2) && (e0 <= t.r2[0]);
-                ok1 = two && inc[0] && (e1 < tp.gather_r2) && (e1 <= t.r2[0]);
-            }
-            if (ok0) {
-                ax[0] += __double_as_longlong(row0[6]); ay[0] += __double_as_longlong(row0[7]); az[0] += __double_as_longlong(row0[8]); am[0]++;
-                if (TAP) {
-                    const unsigned long long ts = atomicAdd(tp.tap_n, 1ull);
-                    if ((int64_t)ts < tp.tap_cap) { tp.tap_key[ts] = (unsigned long long)__double_as_longlong(row0[ROW - 1]); tp.tap_pix[ts] = t.p[0]; }
+        const unsigned long long all_lanes = ballot64(true);
+        for (int ti = 0; ti < ne_u; ti += DEP_EASY_TRIP) {
+            const double* rw[DEP_EASY_TRIP];
+            bool have[DEP_EASY_TRIP];
+            double cc[DEP_EASY_TRIP];
+            bool ok[DEP_EASY_TRIP];
+#pragma unroll
+            for (int u = 0; u < DEP_EASY_TRIP; u++) { have[u] = ti + u < ne_u; rw[u] = s_row[wv][have[u] ? ti + u : ti]; }
+#pragma unroll
+            for (int u = 0; u < DEP_EASY_TRIP; u++) cc[u] = fma(m2z, rw[u][2], fma(m2y, rw[u][1], fma(m2x, rw[u][0], rw[u][3])));
+            // decided: inside or outside by more than the error bound (as wave masks: two compares per record)
+            unsigned long long dec = all_lanes;
+#pragma unroll
+            for (int u = 0; u < DEP_EASY_TRIP; u++) { ok[u] = cc[u] < lo_c; dec &= ballot64(ok[u]) | ballot64(cc[u] > hi_c); ok[u] = ok[u] && have[u]; }
+            if ((all_lanes & ~dec) != 0ull) {
+#pragma unroll
+                for (int u = 0; u < DEP_EASY_TRIP; u++) {
+                    const double e = len2(mk(t.x[0], t.y[0], t.z[0]) - mk(rw[u][7], rw[u][8], rw[u][9]));
+                    ok[u] = have[u] && inc[0] && (e < tp.gather_r2) && (e <= t.r2[0]);
                 }
             }
-            if (ok1) {
-                ax[0] += __double_as_longlong(row1[6]); ay[0] += __double_as_longlong(row1[7]); az[0] += __double_as_longlong(row1[8]); am[0]++;
-                if (TAP) {
-                    const unsigned long long ts = atomicAdd(tp.tap_n, 1ull);
-                    if ((int64_t)ts < tp.tap_cap) { tp.tap_key[ts] = (unsigned long long)__double_as_longlong(row1[ROW - 1]); tp.tap_pix[ts] = t.p[0]; }
+#pragma unroll
+            for (int u = 0; u < DEP_EASY_TRIP; u++) {
+                if (ok[u]) {
+                    ax[0] += __double_as_longlong(rw[u][4]); ay[0] += __double_as_longlong(rw[u][5]); az[0] += __double_as_longlong(rw[u][6]); am[0]++;
+                    if (TAP) {
+                        const unsigned long long ts = atomicAdd(tp.tap_n, 1ull);
+                        if ((int64_t)ts < tp.tap_cap) { tp.tap_key[ts] = (unsigned long long)__double_as_longlong(rw[u][ROW - 1]); tp.tap_pix[ts] = t.p[0]; }
+                    }
                 }
             }
         }
@@ -489,7 +517,6 @@ __global__ void __launch_bounds__(256) DEP_ATTR k_deposit_tiles(HpArrays hp, Rec
         }
         c_acc += (unsigned int)am[h];
     }
-    if (ballot64(clamped) != 0ull && lane == 0) err[6] = 1;
     for (int off = 32; off > 0; off >>= 1) c_acc += __shfl_down(c_acc, off);
     if (lane == 0) {
         if (c_pairs) atomicAdd(&counters[3], c_pairs);
@@ -504,7 +531,7 @@ __global__ void __launch_bounds__(256) DEP_ATTR k_deposit_tiles(HpArrays hp, Rec
     }  // next item
     if (STAMPS && lane == 0) {
         atomicAdd(&counters[16], st_setup); atomicAdd(&counters[17], st_count); atomicAdd(&counters[18], st_issue);
-        atomicAdd(&counters[19], st_append); atomicAdd(&counters[20], st_process); atomicAdd(&counters[21], st_flush);
+        atomicAdd(&counters[19], st_append); atomicAdd(&counters[20], st_process); atomicAdd(&counters[21], st_flush); atomicAdd(&counters[23], st_wait);
     }
 #undef DSTAMP
 }

@@ -109,6 +109,20 @@ __device__ __forceinline__ double first_d(double v)
     const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
     return __hiloint2double(hi, lo);
 }
+// the number of set bits of a wave mask below this lane (v_mbcnt: no per-lane mask register)
+__device__ __forceinline__ unsigned int mbcnt64(unsigned long long m)
+{
+    return __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
+}
+// A wave-uniform double moved into scalar registers for good.  (first_d of a value the compiler can prove uniform is
+// folded away and the value stays in vector registers; this one it cannot see through.)
+__device__ __forceinline__ double pin_scalar_d(double v)
+{
+    int lo, hi;
+    asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(lo) : "v"(__double2loint(v)));
+    asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(hi) : "v"(__double2hiint(v)));
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_max_d(double v)
 {
     for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off));

@@ -2,17 +2,7 @@
 // Part of the single translation unit sppm_kernels.hip (included there, in order; not a stand-alone header).
 #pragma once
 
-// fixed point of the deposits: x * scale (scale a power of two chosen from the emitted flux by sppm_create: the
-// largest emitted component lands in [2^27, 2^28)), rounded to nearest-even, clamped at 2^41 (reported: err[6])
-#define FX_CLAMP 2199023255552.0
-#define FX_MAX_DEPOSITS (1ll << 21)  // per hitpoint and pass: with the clamp a sum stays below 2^62
-__device__ __forceinline__ long long fx_fix(double v, double scale, bool& clamped)
-{
-    double x = v * scale;
-    if (!(x < FX_CLAMP)) { x = FX_CLAMP; clamped = true; }
-    if (x < 0.0) x = 0.0;
-    return __double2ll_rn(x);
-}
+// (fx_fix, the fixed point of the deposits: sppm_records.hpp)
 
 // Pairs (photon-hit record, hitpoint) that the reference's K-capped search dropped (sppm_cap.hpp): an open-addressing
 // table of (record key, hitpoint) entries, filled before the gather starts and only read by it.  n == nullptr or

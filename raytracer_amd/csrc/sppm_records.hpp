@@ -88,8 +88,22 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_add(uint32_t* __restrict__ 
     counts[i] = 0u;
     if (i == n - 1) out[n] = *total;
 }
+// fixed point of the deposits: x * scale (scale a power of two chosen from the emitted flux by sppm_create: the
+// largest emitted component lands in [2^27, 2^28)), rounded to nearest-even, clamped at 2^41 (reported: err[6])
+#define FX_CLAMP 2199023255552.0
+#define FX_MAX_DEPOSITS (1ll << 21)  // per hitpoint and pass: with the clamp a sum stays below 2^62
+__device__ __forceinline__ long long fx_fix(double v, double scale, bool& clamped)
+{
+    double x = v * scale;
+    if (!(x < FX_CLAMP)) { x = FX_CLAMP; clamped = true; }
+    if (x < 0.0) x = 0.0;
+    return __double2ll_rn(x);
+}
+
+// fx_scale > 0 (the per-pass rule's deposit kernel reads dst): the flux planes are written as the 64-bit fixed point of
+// the deposits (fx_fix, bits in the double's place) -- once per record here instead of once per cluster that stages it
 __global__ void k_grid_scatter(RecArrays src, RecArrays dst, const unsigned long long* __restrict__ rec_count,
-                               const uint32_t* __restrict__ rec_bucket, uint32_t* __restrict__ cursor)
+                               const uint32_t* __restrict__ rec_bucket, uint32_t* __restrict__ cursor, double fx_scale, int32_t* __restrict__ err)
 {
     const int64_t n = min((int64_t)*rec_count, src.cap);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -97,6 +111,15 @@ __global__ void k_grid_scatter(RecArrays src, RecArrays dst, const unsigned long
         const uint32_t p = atomicAdd(&cursor[rec_bucket[i]], 1u);
         dst.key[p] = src.key[i];
 #pragma unroll
-        for (int c = 0; c < 9; c++) dst.f[c * dst.cap + p] = src.f[c * src.cap + i];
+        for (int c = 0; c < 6; c++) dst.f[c * dst.cap + p] = src.f[c * src.cap + i];
+        if (fx_scale > 0.0) {
+            bool clamped = false;
+#pragma unroll
+            for (int c = 6; c < 9; c++) dst.f[c * dst.cap + p] = __longlong_as_double(fx_fix(src.f[c * src.cap + i], fx_scale, clamped));
+            if (clamped) err[6] = 1;
+        } else {
+#pragma unroll
+            for (int c = 6; c < 9; c++) dst.f[c * dst.cap + p] = src.f[c * src.cap + i];
+        }
     }
 }
