@@ -169,9 +169,6 @@ __global__ void __launch_bounds__(256) k_deposit_plan(HpArrays hp, const uint32_
     if (lane == 0) { est[k] = total; n_pieces[k] = (uint8_t)n_out; }
 }
 
-#ifndef DEP_EASY_TRIP
-#define DEP_EASY_TRIP 2  // records of the distance-only class per trip of their loop (independent chains of LDS read -> three fused multiply-adds -> compare)
-#endif
 #ifndef DEP_WAVES
 #define DEP_WAVES (DEP_H == 1 ? 4 : 3)  // register budget: 512 / DEP_WAVES per lane
 #endif
@@ -411,40 +408,48 @@ __global__ void __launch_bounds__(256) DEP_ATTR k_deposit_tiles(HpArrays hp, Rec
         __builtin_amdgcn_wave_barrier();
         c_sel += (unsigned int)sel_n; c_pairs += (unsigned long long)sel_n * R.n_inc; c_round++;
         const int ne_u = __builtin_amdgcn_readfirstlane(n_easy), nf_u = __builtin_amdgcn_readfirstlane(n_full);
-        // rows [0, n_easy): the normal and flatness tests pass for the whole cluster, the distance test alone decides;
-        // two records per trip (independent chains of LDS read -> subtract -> square -> compare)
-        const unsigned long long all_lanes = ballot64(true);
-        for (int ti = 0; ti < ne_u; ti += DEP_EASY_TRIP) {
-            const double* rw[DEP_EASY_TRIP];
-            bool have[DEP_EASY_TRIP];
-            double cc[DEP_EASY_TRIP];
-            bool ok[DEP_EASY_TRIP];
-#pragma unroll
-            for (int u = 0; u < DEP_EASY_TRIP; u++) { have[u] = ti + u < ne_u; rw[u] = s_row[wv][have[u] ? ti + u : ti]; }
-#pragma unroll
-            for (int u = 0; u < DEP_EASY_TRIP; u++) cc[u] = fma(m2z, rw[u][2], fma(m2y, rw[u][1], fma(m2x, rw[u][0], rw[u][3])));
-            // decided: inside or outside by more than the error bound (as wave masks: two compares per record)
-            unsigned long long dec = all_lanes;
-#pragma unroll
-            for (int u = 0; u < DEP_EASY_TRIP; u++) { ok[u] = cc[u] < lo_c; dec &= ballot64(ok[u]) | ballot64(cc[u] > hi_c); ok[u] = ok[u] && have[u]; }
-            if ((all_lanes & ~dec) != 0ull) {
-#pragma unroll
-                for (int u = 0; u < DEP_EASY_TRIP; u++) {
-                    const double e = len2(mk(t.x[0], t.y[0], t.z[0]) - mk(rw[u][7], rw[u][8], rw[u][9]));
-                    ok[u] = have[u] && inc[0] && (e < tp.gather_r2) && (e <= t.r2[0]);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < DEP_EASY_TRIP; u++) {
-                if (ok[u]) {
-                    ax[0] += __double_as_longlong(rw[u][4]); ay[0] += __double_as_longlong(rw[u][5]); az[0] += __double_as_longlong(rw[u][6]); am[0]++;
-                    if (TAP) {
-                        const unsigned long long ts = atomicAdd(tp.tap_n, 1ull);
-                        if ((int64_t)ts < tp.tap_cap) { tp.tap_key[ts] = (unsigned long long)__double_as_longlong(rw[u][ROW - 1]); tp.tap_pix[ts] = t.p[0]; }
-                    }
+        // rows [0, n_easy): the normal and flatness tests pass for the whole cluster, the distance test alone decides.
+        // Two records per trip (independent chains of LDS read -> three fused multiply-adds -> compares); a pair too
+        // close to call (see E above) is left out here and only noted in `und` -- the loop carries no branch for it.
+#define DEP_TAKE(rowp)                                                                                                 \
+        {                                                                                                              \
+            ax[0] += __double_as_longlong((rowp)[4]); ay[0] += __double_as_longlong((rowp)[5]); az[0] += __double_as_longlong((rowp)[6]); am[0]++; \
+            if (TAP) {                                                                                                 \
+                const unsigned long long ts = atomicAdd(tp.tap_n, 1ull);                                               \
+                if ((int64_t)ts < tp.tap_cap) { tp.tap_key[ts] = (unsigned long long)__double_as_longlong((rowp)[ROW - 1]); tp.tap_pix[ts] = t.p[0]; } \
+            }                                                                                                          \
+        }
+        unsigned long long und = 0ull;
+        int ti = 0;
+        for (; ti + 1 < ne_u; ti += 2) {
+            const double* r0 = s_row[wv][ti];
+            const double* r1 = s_row[wv][ti + 1];
+            const double c0 = fma(m2z, r0[2], fma(m2y, r0[1], fma(m2x, r0[0], r0[3])));
+            const double c1 = fma(m2z, r1[2], fma(m2y, r1[1], fma(m2x, r1[0], r1[3])));
+            const bool ok0 = c0 < lo_c, ok1 = c1 < lo_c;
+            und |= ~(ballot64(ok0) | ballot64(c0 > hi_c)) | ~(ballot64(ok1) | ballot64(c1 > hi_c));
+            if (ok0) DEP_TAKE(r0)
+            if (ok1) DEP_TAKE(r1)
+        }
+        if (ti < ne_u) {
+            const double* r0 = s_row[wv][ti];
+            const double c0 = fma(m2z, r0[2], fma(m2y, r0[1], fma(m2x, r0[0], r0[3])));
+            const bool ok0 = c0 < lo_c;
+            und |= ~(ballot64(ok0) | ballot64(c0 > hi_c));
+            if (ok0) DEP_TAKE(r0)
+        }
+        if ((und & ballot64(true)) != 0ull) {
+            // (once in ~10^9 pairs) the pairs left out: decided from the positions themselves, in the reference's operation order
+            for (int tj = 0; tj < ne_u; tj++) {
+                const double* row = s_row[wv][tj];
+                const double c0 = fma(m2z, row[2], fma(m2y, row[1], fma(m2x, row[0], row[3])));
+                if (!(c0 < lo_c) && !(c0 > hi_c)) {
+                    const double e = len2(mk(t.x[0], t.y[0], t.z[0]) - mk(row[7], row[8], row[9]));
+                    if (inc[0] && (e < tp.gather_r2) && (e <= t.r2[0])) DEP_TAKE(row)
                 }
             }
         }
+#undef DEP_TAKE
         // rows [64 - n_full, 64): the full test
         for (int ti = DEP_ROWS - nf_u; ti < DEP_ROWS; ti++) {
             const double* row = s_row[wv][ti];
