@@ -188,7 +188,6 @@ __global__ void __launch_bounds__(256) DEP_ATTR k_deposit_tiles(HpArrays hp, Rec
     const double thr = tp.gather_r2 * 0.01;
     const double band_rel = 1e-9 + 8e-15 / thr;
     const double thr2_lo = thr * thr * (1.0 - band_rel), thr2_hi = thr * thr * (1.0 + band_rel);
-    const int64_t cap = rec.cap;
     const unsigned int n_items = q[0];
     const unsigned int n_waves = gridDim.x * 4u;
 #define DSTAMP() (STAMPS ? (unsigned long long)__builtin_amdgcn_s_memtime() : 0ull)
@@ -346,10 +345,10 @@ __global__ void __launch_bounds__(256) DEP_ATTR k_deposit_tiles(HpArrays hp, Rec
             }                                                                                                          \
             p_r = __shfl(g_cs, j) + (i - __shfl(g_pre, j));                                                            \
             if (p_has) {                                                                                               \
-                p0 = rec.f[p_r]; p1 = rec.f[cap + p_r]; p2 = rec.f[2 * cap + p_r];                                     \
-                p3 = rec.f[3 * cap + p_r]; p4 = rec.f[4 * cap + p_r]; p5 = rec.f[5 * cap + p_r];                       \
-                p6 = rec.f[6 * cap + p_r]; p7 = rec.f[7 * cap + p_r]; p8 = rec.f[8 * cap + p_r];                       \
-                if (TAP) p_key = rec.key[p_r];                                                                         \
+                const double2* rp = (const double2*)(rec.f + (size_t)REC_ROW * p_r);  /* one row: sppm_records.hpp */   \
+                const double2 ra = rp[0], rb = rp[1], rc = rp[2], rd = rp[3], re = rp[4];                              \
+                p0 = ra.x; p1 = ra.y; p2 = rb.x; p3 = rb.y; p4 = rc.x; p5 = rc.y; p6 = rd.x; p7 = rd.y; p8 = re.x;     \
+                if (TAP) p_key = (unsigned long long)__double_as_longlong(re.y);                                       \
             }                                                                                                          \
             cbase += 64;                                                                                               \
         }                                                                                                              \

@@ -504,7 +504,7 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
     for (int b = 0; b < (c->gather_mode ? NBUF : 1); b++) {
         sppm_ctx::BinSet& B = c->bins[b];
         B.rec_s.cap = cap; B.binned = 0;
-        TRY(dev_alloc(c, &B.rec_s.key, (size_t)cap, false)); TRY(dev_alloc(c, &B.rec_s.f, 9 * (size_t)cap, false));
+        TRY(dev_alloc(c, &B.rec_s.key, (size_t)cap, false)); TRY(dev_alloc(c, &B.rec_s.f, REC_ROW * (size_t)cap, false));  // (nine planes, or rows of REC_ROW: k_grid_scatter)
         TRY(dev_alloc(c, &B.rec_bucket, (size_t)cap, false));
         TRY(dev_alloc(c, &B.cell_cnt, (size_t)nb)); TRY(dev_alloc(c, &B.cell_start, (size_t)nb + 1)); TRY(dev_alloc(c, &B.cursor, (size_t)nb));
         TRY(dev_alloc(c, &B.block_sum, (size_t)nb / SCAN_BLOCK + 1)); TRY(dev_alloc(c, &B.total, 1));

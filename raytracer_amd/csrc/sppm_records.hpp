@@ -100,8 +100,12 @@ __device__ __forceinline__ long long fx_fix(double v, double scale, bool& clampe
     return __double2ll_rn(x);
 }
 
-// fx_scale > 0 (the per-pass rule's deposit kernel reads dst): the flux planes are written as the 64-bit fixed point of
-// the deposits (fx_fix, bits in the double's place) -- once per record here instead of once per cluster that stages it
+// fx_scale > 0 (the per-pass rule's deposit kernel reads dst): the flux is written as the 64-bit fixed point of the
+// deposits (fx_fix, bits in the double's place) -- once per record here instead of once per cluster that stages it --
+// and dst is laid out record by record, REC_ROW doubles each: position, geometric normal, flux bits, key.  The deposit
+// kernel reads every record of a cell region about fifty times, a few consecutive records at a time: as rows those are
+// one or two cache lines, as nine planes nine.
+#define REC_ROW 10
 __global__ void k_grid_scatter(RecArrays src, RecArrays dst, const unsigned long long* __restrict__ rec_count,
                                const uint32_t* __restrict__ rec_bucket, uint32_t* __restrict__ cursor, double fx_scale, int32_t* __restrict__ err)
 {
@@ -109,17 +113,22 @@ __global__ void k_grid_scatter(RecArrays src, RecArrays dst, const unsigned long
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         if (rec_bucket[i] == 0xFFFFFFFFu) continue;
         const uint32_t p = atomicAdd(&cursor[rec_bucket[i]], 1u);
-        dst.key[p] = src.key[i];
-#pragma unroll
-        for (int c = 0; c < 6; c++) dst.f[c * dst.cap + p] = src.f[c * src.cap + i];
         if (fx_scale > 0.0) {
             bool clamped = false;
+            double v[REC_ROW];
 #pragma unroll
-            for (int c = 6; c < 9; c++) dst.f[c * dst.cap + p] = __longlong_as_double(fx_fix(src.f[c * src.cap + i], fx_scale, clamped));
+            for (int c = 0; c < 6; c++) v[c] = src.f[c * src.cap + i];
+#pragma unroll
+            for (int c = 6; c < 9; c++) v[c] = __longlong_as_double(fx_fix(src.f[c * src.cap + i], fx_scale, clamped));
+            v[9] = __longlong_as_double((long long)src.key[i]);
+            double2* row = (double2*)(dst.f + (size_t)REC_ROW * p);
+#pragma unroll
+            for (int c = 0; c < REC_ROW / 2; c++) row[c] = make_double2(v[2 * c], v[2 * c + 1]);
             if (clamped) err[6] = 1;
         } else {
+            dst.key[p] = src.key[i];
 #pragma unroll
-            for (int c = 6; c < 9; c++) dst.f[c * dst.cap + p] = src.f[c * src.cap + i];
+            for (int c = 0; c < 9; c++) dst.f[c * dst.cap + p] = src.f[c * src.cap + i];
         }
     }
 }
