@@ -99,15 +99,25 @@ __device__ __forceinline__ unsigned long long spread3(unsigned long long x)  // 
 }
 // Morton code, MORTON_BITS bits per axis over the bounding box (ties keep pixel order: the sort is stable);
 // invalid hitpoints sort last
+typedef uint32_t hp_key_t;
+#ifndef MORTON_BITS
 #define MORTON_BITS 10
+#endif
+#ifdef MORTON_INVALID_MAX
+#define MORTON_KEY_BITS (3 * MORTON_BITS)
+#define MORTON_INVALID (((hp_key_t)1u << (3 * MORTON_BITS)) - 1u)
+#else
+#define MORTON_KEY_BITS (3 * MORTON_BITS + 1)  // (+1: the invalid hitpoints' key)
+#define MORTON_INVALID ((hp_key_t)1u << (3 * MORTON_BITS))
+#endif
 #define MORTON_MAX ((double)((1 << MORTON_BITS) - 1))
 __global__ void k_hp_sortkeys(HpArrays hp, const int32_t* __restrict__ pix, int n, const unsigned long long* __restrict__ bb,
-                              unsigned long long* __restrict__ keys)
+                              hp_key_t* __restrict__ keys)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int p = pix[i], P = hp.P;
-    if (!hp.valid[p]) { keys[i] = (1ull << (3 * MORTON_BITS)); return; }
+    if (!hp.valid[p]) { keys[i] = MORTON_INVALID; return; }
     unsigned long long code = 0;
     for (int a = 0; a < 3; a++) {
         const double lo = undo_ord_d(bb[a]), hi = undo_ord_d(bb[3 + a]);
@@ -116,7 +126,7 @@ __global__ void k_hp_sortkeys(HpArrays hp, const int32_t* __restrict__ pix, int 
         f = f < 0.0 ? 0.0 : (f > MORTON_MAX ? MORTON_MAX : f);
         code |= spread3((unsigned long long)f) << a;
     }
-    keys[i] = code;
+    keys[i] = (hp_key_t)code;
 }
 
 // (slab, cell) bucket of every record of the batch
@@ -391,7 +401,6 @@ __global__ void __launch_bounds__(256) GATHER_WAVES_ATTR k_gather_tiles(HpArrays
     const double thr = tp.gather_r2 * 0.01;
     const double band_rel = 1e-9 + 8e-15 / thr;
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    const int64_t cap = rec.cap;
     // Persistent wavefronts: wave w starts with item w (thousands of waves asking one counter at the same
     // moment would queue up for a millisecond), then each takes the next item of the ordered list until the
     // list is empty (q[0] = number of items, q[1] = queue head beyond the first gridDim.x*4; every wave
@@ -502,10 +511,12 @@ __global__ void __launch_bounds__(256) GATHER_WAVES_ATTR k_gather_tiles(HpArrays
                     bool in = false;
                     unsigned long long key = 0;
                     if (has) {
-                        key = rec.key[r];
+                        const double2* rp = (const double2*)(rec.f + (size_t)REC_ROW * r);  // one row: sppm_records.hpp
+                        key = (unsigned long long)__double_as_longlong(rp[4].y);
                         in = key >= klo && key < khi;
                         if (in) {
-                            const double qx = rec.f[r], qy = rec.f[cap + r], qz = rec.f[2 * cap + r];
+                            const double2 ra = rp[0];
+                            const double qx = ra.x, qy = ra.y, qz = rp[1].x;
                             in = qx >= lx && qx <= hx && qy >= ly && qy <= hy && qz >= lz && qz <= hz;
                         }
                     }
@@ -536,9 +547,9 @@ __global__ void __launch_bounds__(256) GATHER_WAVES_ATTR k_gather_tiles(HpArrays
                 if (own) {
                     mykey = s_key[wv][lane];
                     const uint32_t r = s_rec[wv][lane];
-                    q = mk(rec.f[r], rec.f[cap + r], rec.f[2 * cap + r]);
-                    gn = mk(rec.f[3 * cap + r], rec.f[4 * cap + r], rec.f[5 * cap + r]);
-                    pf = mk(rec.f[6 * cap + r], rec.f[7 * cap + r], rec.f[8 * cap + r]);
+                    const double2* rp = (const double2*)(rec.f + (size_t)REC_ROW * r);
+                    const double2 ra = rp[0], rb = rp[1], rc = rp[2], rd = rp[3], re = rp[4];
+                    q = mk(ra.x, ra.y, rb.x); gn = mk(rb.y, rc.x, rc.y); pf = mk(rd.x, rd.y, re.x);
                 }
                 int rank = 0;
                 for (int jj = 0; jj < sel_n; jj++) rank += (s_key[wv][jj] < mykey) ? 1 : 0;

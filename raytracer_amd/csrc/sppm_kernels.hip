@@ -88,7 +88,7 @@ struct sppm_ctx {
     int32_t *d_own_pix, *d_order; int n_own_pix;
     uint8_t* d_own_mask;   // [P]
     int own_pending;       // spatial ownership: the pixel list is cut out of the first eye pass's Morton order
-    unsigned long long *d_hp_keys, *d_hp_keys_out, *d_hp_bb;
+    hp_key_t *d_hp_keys, *d_hp_keys_out; unsigned long long* d_hp_bb;
     void* d_sort_tmp; size_t sort_tmp_bytes;
     uint32_t *d_cell_tot, *d_est, *d_items; unsigned long long* d_items_raw; unsigned int* d_item_q; uint8_t* d_n_pieces; unsigned long long* d_est_sum; uint8_t* d_ext_bin; int est_valid;  // d_item_q: [0] items [1] queue head [2..33] per cost class
     double split_factor, est_per_photon; int64_t est_range;
@@ -212,7 +212,7 @@ static int dev_alloc(sppm_ctx* c, T** p, size_t n, bool zero = true)
 }
 
 // The sort of the hitpoints' Morton keys runs beside the gather, whose persistent wavefronts leave one wavefront slot of
-// 128 registers per SIMD.  rocPRIM's tuned Onesweep kernel for (64-bit key, 32-bit value) uses workgroups of 512 threads,
+// 128 registers per SIMD.  rocPRIM's tuned Onesweep kernel for these keys and values uses workgroups of 512 threads,
 // two wavefronts per SIMD, which found no room until the gather's tail (one pass of it took 2.4 ms instead of 40 us).
 // The same algorithm (8 bits per pass, match-based ranking) with workgroups of 256 threads fits.
 typedef rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
@@ -568,7 +568,7 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
         { const char* e = getenv("SPPM_SPLIT_FACTOR"); if (e && *e) c->split_factor = atof(e); }
         if (c->n_own_pix > 0) {
             if (rocprim::radix_sort_pairs<HpSortConfig>(nullptr, c->sort_tmp_bytes, c->d_hp_keys, c->d_hp_keys_out, c->d_own_pix, c->d_order,
-                                          (size_t)c->n_own_pix, 0, 3 * MORTON_BITS + 1, c->stream) != hipSuccess) {
+                                          (size_t)c->n_own_pix, 0, MORTON_KEY_BITS, c->stream) != hipSuccess) {
                 sppm_destroy(c); return fail(SPPM_ERR_HIP, "sizing the hitpoint sort failed");
             }
             char* tmp = nullptr;
@@ -867,7 +867,7 @@ static int eye_launch(sppm_ctx* c, int32_t pass, hipStream_t st)
         hipLaunchKernelGGL(k_hp_sortkeys, dim3(nblk(c->n_own_pix, 256)), dim3(256), 0, st, c->view[nv], c->d_own_pix, c->n_own_pix, c->d_hp_bb_r[slot], c->d_hp_keys);
         HIPCHK(hipGetLastError());
         HIPCHK(rocprim::radix_sort_pairs<HpSortConfig>(c->d_sort_tmp, c->sort_tmp_bytes, c->d_hp_keys, c->d_hp_keys_out, c->d_own_pix, c->d_order_r[slot],
-                                         (size_t)c->n_own_pix, 0, 3 * MORTON_BITS + 1, st));
+                                         (size_t)c->n_own_pix, 0, MORTON_KEY_BITS, st));
         if (c->own_pending) {
             // Spatial ownership: this rank keeps positions [rank*P/N, (rank+1)*P/N) of the order just made
             // (every rank computes the same order from the same eye pass, so the ranges partition the
@@ -1242,7 +1242,7 @@ static int gather_simple(sppm_ctx* c)
     hipLaunchKernelGGL(k_grid_count, dim3(2048), dim3(256), 0, st, c->rec_u, c->d_rec_count, g, c->d_cell_cnt, c->d_rec_bucket);
     int rc = run_scan(c, c->bins[c->cur], nb, st, nullptr);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_grid_scatter, dim3(2048), dim3(256), 0, st, c->rec_u, c->rec_s, c->d_rec_count, c->d_rec_bucket, c->d_cursor, 0.0, c->d_err);
+    hipLaunchKernelGGL(k_grid_scatter, dim3(2048), dim3(256), 0, st, c->rec_u, c->rec_s, c->d_rec_count, c->d_rec_bucket, c->d_cursor, 0, 0.0, c->d_err);
     GatherParams gp;
     gp.g = g; gp.gather_r2 = c->cfg.gather_radius2; gp.alpha = c->cfg.alpha; gp.rule = c->cfg.update_rule;
     gp.own = own_of(c); gp.unit_weight = c->algo; gp.fx_scale = c->fx_scale; gp.err = c->d_err;
@@ -1369,7 +1369,7 @@ static int bin_into(sppm_ctx* c, int b, const TileGrid& g, hipStream_t st, bool 
                        near_map(c, drop_far));
     int rc = run_scan(c, B, n_padded, st, c->d_counters + 2);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_grid_scatter, dim3(bin_blocks), dim3(256), 0, st, c->rec_buf[b], B.rec_s, c->d_rec_count_buf[b], B.rec_bucket, B.cursor,
+    hipLaunchKernelGGL(k_grid_scatter, dim3(bin_blocks), dim3(256), 0, st, c->rec_buf[b], B.rec_s, c->d_rec_count_buf[b], B.rec_bucket, B.cursor, 1,
                        c->cfg.update_rule == 1 ? c->fx_scale : 0.0, c->d_err);  // (rule 1 here: deposit_tiles is the reader)
     HIPCHK(hipGetLastError());
     B.g = g; B.binned = 1;

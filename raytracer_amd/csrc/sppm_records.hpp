@@ -100,26 +100,28 @@ __device__ __forceinline__ long long fx_fix(double v, double scale, bool& clampe
     return __double2ll_rn(x);
 }
 
-// fx_scale > 0 (the per-pass rule's deposit kernel reads dst): the flux is written as the 64-bit fixed point of the
-// deposits (fx_fix, bits in the double's place) -- once per record here instead of once per cluster that stages it --
-// and dst is laid out record by record, REC_ROW doubles each: position, geometric normal, flux bits, key.  The deposit
-// kernel reads every record of a cell region about fifty times, a few consecutive records at a time: as rows those are
-// one or two cache lines, as nine planes nine.
+// rows != 0 (the tile gathers read dst): dst is laid out record by record, REC_ROW doubles each: position, geometric
+// normal, flux, key.  The gathers read every record of a cell region many times, a few consecutive records at a time: as
+// rows those are one or two cache lines, as nine planes nine -- and this kernel writes 80 contiguous bytes per record.
+// fx_scale > 0 (the per-pass rule's deposit kernel): the flux is written as the 64-bit fixed point of the deposits
+// (fx_fix, bits in the double's place) -- once per record here instead of once per cluster that stages it.
 #define REC_ROW 10
 __global__ void k_grid_scatter(RecArrays src, RecArrays dst, const unsigned long long* __restrict__ rec_count,
-                               const uint32_t* __restrict__ rec_bucket, uint32_t* __restrict__ cursor, double fx_scale, int32_t* __restrict__ err)
+                               const uint32_t* __restrict__ rec_bucket, uint32_t* __restrict__ cursor, int rows, double fx_scale, int32_t* __restrict__ err)
 {
     const int64_t n = min((int64_t)*rec_count, src.cap);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         if (rec_bucket[i] == 0xFFFFFFFFu) continue;
         const uint32_t p = atomicAdd(&cursor[rec_bucket[i]], 1u);
-        if (fx_scale > 0.0) {
+        if (rows) {
             bool clamped = false;
             double v[REC_ROW];
 #pragma unroll
-            for (int c = 0; c < 6; c++) v[c] = src.f[c * src.cap + i];
+            for (int c = 0; c < 9; c++) v[c] = src.f[c * src.cap + i];
+            if (fx_scale > 0.0) {
 #pragma unroll
-            for (int c = 6; c < 9; c++) v[c] = __longlong_as_double(fx_fix(src.f[c * src.cap + i], fx_scale, clamped));
+                for (int c = 6; c < 9; c++) v[c] = __longlong_as_double(fx_fix(v[c], fx_scale, clamped));
+            }
             v[9] = __longlong_as_double((long long)src.key[i]);
             double2* row = (double2*)(dst.f + (size_t)REC_ROW * p);
 #pragma unroll
