@@ -265,7 +265,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
 {
     STAGE_SCENE_T(sc, GRID);
     const int lane = threadIdx.x & 63;
-    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const int P = ep.W * ep.H;
     const bool blocks8 = ((ep.W | ep.H) & 7) == 0;
     uint32_t rays = 0;
@@ -287,7 +286,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
                 blk_hi = min((long long)base + 64, (long long)P);
                 if (blk_lo >= P) { exhausted = true; blk_lo = blk_hi = 0; }
             }
-            const long long idx = blk_lo + __popcll(need & lt_mask);
+            const long long idx = blk_lo + (long long)mbcnt64(need);
             if (!active && idx < blk_hi) {
                 int t = (int)idx;
                 if (blocks8) {

@@ -400,7 +400,6 @@ __global__ void __launch_bounds__(256) GATHER_WAVES_ATTR k_gather_tiles(HpArrays
     const double BIG = 1e300;
     const double thr = tp.gather_r2 * 0.01;
     const double band_rel = 1e-9 + 8e-15 / thr;
-    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     // Persistent wavefronts: wave w starts with item w (thousands of waves asking one counter at the same
     // moment would queue up for a millisecond), then each takes the next item of the ordered list until the
     // list is empty (q[0] = number of items, q[1] = queue head beyond the first gridDim.x*4; every wave
@@ -525,7 +524,7 @@ __global__ void __launch_bounds__(256) GATHER_WAVES_ATTR k_gather_tiles(HpArrays
                     const int cnt = __popcll(m);
                     if (sel_n + cnt > 64) { overflow = true; break; }
                     if (in) {
-                        const int slot = sel_n + __popcll(m & lt_mask);
+                        const int slot = sel_n + (int)mbcnt64(m);
                         s_key[wv][slot] = key;
                         s_rec[wv][slot] = r;
                     }

@@ -133,7 +133,6 @@ __global__ void __launch_bounds__(256) TRACE_ATTR k_photon_trace(DevScene sc, Tr
     typedef typename TraceRng<MODE>::type RNG;
     STAGE_SCENE_T(sc, GRID);
     const int lane = threadIdx.x & 63;
-    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     uint32_t rays = 0;
     PhotonState<RNG> ps;
     ps.depth = 0; ps.index = 0; ps.org = mk(0, 0, 0); ps.dir = mk(0, 0, 1); ps.flux = mk(0, 0, 0);
@@ -154,7 +153,7 @@ __global__ void __launch_bounds__(256) TRACE_ATTR k_photon_trace(DevScene sc, Tr
                 blk_hi = min((int64_t)base + TRACE_GRAB, tp.count);
                 if (blk_lo >= tp.count) { exhausted = true; blk_lo = blk_hi = 0; }
             }
-            const int64_t idx = blk_lo + __popcll(need & lt_mask);
+            const int64_t idx = blk_lo + (int64_t)mbcnt64(need);
             if (!active && idx < blk_hi) { photon_emit<MODE>(sc, tp, tp.first + idx, ps); active = true; }
             blk_lo = min(blk_hi, blk_lo + (int64_t)__popcll(need));
         }
@@ -238,7 +237,7 @@ __global__ void __launch_bounds__(256) TRACE_ATTR k_photon_trace(DevScene sc, Tr
             }
             if (!rec_full) {
                 if (dep.want) {
-                    const int64_t slot = chunk_lo + __popcll(dm & lt_mask);
+                    const int64_t slot = chunk_lo + (int64_t)mbcnt64(dm);
                     rec.key[slot] = dep.key;
                     double* f = rec.f + slot;
                     const int64_t c = rec.cap;
