@@ -123,12 +123,39 @@ __device__ __forceinline__ double pin_scalar_d(double v)
     asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(hi) : "v"(__double2hiint(v)));
     return __hiloint2double(hi, lo);
 }
+// min / max over the wavefront by data-parallel primitives (DPP) instead of LDS permutes: four shifts within each row of
+// 16 lanes, then the rows' last lanes broadcast to the rows after them; lane 63 ends up with the result.  (A lane whose
+// DPP source does not exist keeps its own value: min and max are idempotent.)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_d(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), CTRL, ROW_MASK, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), CTRL, ROW_MASK, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_max_d(double v)
+{
+    v = fmax(v, dpp_d<0x111, 0xF>(v)); v = fmax(v, dpp_d<0x112, 0xF>(v)); v = fmax(v, dpp_d<0x114, 0xF>(v)); v = fmax(v, dpp_d<0x118, 0xF>(v));  // row_shr 1, 2, 4, 8
+    v = fmax(v, dpp_d<0x142, 0xA>(v));  // row_bcast 15 into rows 1 and 3
+    v = fmax(v, dpp_d<0x143, 0xC>(v));  // row_bcast 31 into rows 2 and 3
+    return rl_d(v, 63);
+}
+__device__ __forceinline__ double wave_min_d(double v)
+{
+    v = fmin(v, dpp_d<0x111, 0xF>(v)); v = fmin(v, dpp_d<0x112, 0xF>(v)); v = fmin(v, dpp_d<0x114, 0xF>(v)); v = fmin(v, dpp_d<0x118, 0xF>(v));
+    v = fmin(v, dpp_d<0x142, 0xA>(v));
+    v = fmin(v, dpp_d<0x143, 0xC>(v));
+    return rl_d(v, 63);
+}
+
+// the same by LDS permutes (the ordered gather keeps these: with the DPP forms its register allocation came out worse
+// and the kernel 7 % slower)
+__device__ __forceinline__ double wave_max_perm_d(double v)
 {
     for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off));
     return first_d(v);
 }
-__device__ __forceinline__ double wave_min_d(double v)
+__device__ __forceinline__ double wave_min_perm_d(double v)
 {
     for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off));
     return first_d(v);

@@ -42,7 +42,7 @@ struct TileParams {
     unsigned long long* item_times;  // diagnostic (SPPM_ITEM_TIMES): start/end clock of every work item
 };
 
-// (rl_d, first_d, wave_min_d, wave_max_d: sppm_device.hpp)
+// (rl_d, first_d, wave_min_perm_d, wave_max_perm_d: sppm_device.hpp)
 // grid coordinate of x, clamped to [0, n-1]; monotone in x, so an interval maps to an index range
 __device__ __forceinline__ int grid_coord(double x, double o, double inv_c, int n)
 {
@@ -168,10 +168,10 @@ __global__ void __launch_bounds__(256) k_tile_extent(HpArrays hp, TileParams tp,
     const double BIG = 1e300;
     const double x = live ? hp.pos[p] : 0.0, y = live ? hp.pos[P + p] : 0.0, z = live ? hp.pos[2 * P + p] : 0.0;
     const double r = live ? sqrt(fmin(hp.r2[p], tp.gather_r2)) : 0.0;
-    const double x0 = wave_min_d(live ? x : BIG), x1 = wave_max_d(live ? x : -BIG);
-    const double y0 = wave_min_d(live ? y : BIG), y1 = wave_max_d(live ? y : -BIG);
-    const double z0 = wave_min_d(live ? z : BIG), z1 = wave_max_d(live ? z : -BIG);
-    const double rm = wave_max_d(r);
+    const double x0 = wave_min_perm_d(live ? x : BIG), x1 = wave_max_perm_d(live ? x : -BIG);
+    const double y0 = wave_min_perm_d(live ? y : BIG), y1 = wave_max_perm_d(live ? y : -BIG);
+    const double z0 = wave_min_perm_d(live ? z : BIG), z1 = wave_max_perm_d(live ? z : -BIG);
+    const double rm = wave_max_perm_d(r);
     if (lane == 0) {
         const double ext = fmax(x1 - x0, fmax(y1 - y0, z1 - z0)) + 2.0 * rm;
         int e;
@@ -310,10 +310,10 @@ __global__ void __launch_bounds__(256) k_tile_plan(HpArrays hp, const uint32_t* 
             const double sx = rl_d(x, seed), sy = rl_d(y, seed), sz = rl_d(z, seed);
             const bool inc = in && ((remaining >> lane) & 1ull) && fabs(x - sx) <= tp.cluster_d && fabs(y - sy) <= tp.cluster_d && fabs(z - sz) <= tp.cluster_d;
             remaining &= ~__ballot(inc);
-            const double rm = wave_max_d(inc ? rr : 0.0);
-            const int cx0 = grid_coord(wave_min_d(inc ? x : BIG) - rm, tp.g.ox, tp.g.inv_c, tp.g.nx), cx1 = grid_coord(wave_max_d(inc ? x : -BIG) + rm, tp.g.ox, tp.g.inv_c, tp.g.nx);
-            const int cy0 = grid_coord(wave_min_d(inc ? y : BIG) - rm, tp.g.oy, tp.g.inv_c, tp.g.ny), cy1 = grid_coord(wave_max_d(inc ? y : -BIG) + rm, tp.g.oy, tp.g.inv_c, tp.g.ny);
-            const int cz0 = grid_coord(wave_min_d(inc ? z : BIG) - rm, tp.g.oz, tp.g.inv_c, tp.g.nz), cz1 = grid_coord(wave_max_d(inc ? z : -BIG) + rm, tp.g.oz, tp.g.inv_c, tp.g.nz);
+            const double rm = wave_max_perm_d(inc ? rr : 0.0);
+            const int cx0 = grid_coord(wave_min_perm_d(inc ? x : BIG) - rm, tp.g.ox, tp.g.inv_c, tp.g.nx), cx1 = grid_coord(wave_max_perm_d(inc ? x : -BIG) + rm, tp.g.ox, tp.g.inv_c, tp.g.nx);
+            const int cy0 = grid_coord(wave_min_perm_d(inc ? y : BIG) - rm, tp.g.oy, tp.g.inv_c, tp.g.ny), cy1 = grid_coord(wave_max_perm_d(inc ? y : -BIG) + rm, tp.g.oy, tp.g.inv_c, tp.g.ny);
+            const int cz0 = grid_coord(wave_min_perm_d(inc ? z : BIG) - rm, tp.g.oz, tp.g.inv_c, tp.g.nz), cz1 = grid_coord(wave_max_perm_d(inc ? z : -BIG) + rm, tp.g.oz, tp.g.inv_c, tp.g.nz);
             sum += sat_box(cell_tot, tp.g.nx, tp.g.ny, cx0, cx1, cy0, cy1, cz0, cz1, lane);
             // every slab of every cluster walks the region's cells whether they hold records or not: a fixed
             // part worth ~16 records, and 64 cells ~ 16 records of work
@@ -458,13 +458,13 @@ __global__ void __launch_bounds__(256) GATHER_WAVES_ATTR k_gather_tiles(HpArrays
                      fabs(hpos.z - sz) <= tp.cluster_d;
     remaining &= ~__ballot(inc);
     const unsigned int n_inc = (unsigned int)__popcll(__ballot(inc));
-    const double bx0 = wave_min_d(inc ? hpos.x : BIG), bx1 = wave_max_d(inc ? hpos.x : -BIG);
-    const double by0 = wave_min_d(inc ? hpos.y : BIG), by1 = wave_max_d(inc ? hpos.y : -BIG);
-    const double bz0 = wave_min_d(inc ? hpos.z : BIG), bz1 = wave_max_d(inc ? hpos.z : -BIG);
+    const double bx0 = wave_min_perm_d(inc ? hpos.x : BIG), bx1 = wave_max_perm_d(inc ? hpos.x : -BIG);
+    const double by0 = wave_min_perm_d(inc ? hpos.y : BIG), by1 = wave_max_perm_d(inc ? hpos.y : -BIG);
+    const double bz0 = wave_min_perm_d(inc ? hpos.z : BIG), bz1 = wave_max_perm_d(inc ? hpos.z : -BIG);
     for (int s = 0; s < tp.g.S; s++) {
         // region of this slab: bounding box grown by the largest radius any lane can still accept at
         const double rr = inc ? sqrt(fmin(r2, tp.gather_r2)) * (1.0 + 1e-9) + 1e-9 : 0.0;
-        const double rmax = wave_max_d(rr);
+        const double rmax = wave_max_perm_d(rr);
         const double lx = bx0 - rmax, hx = bx1 + rmax, ly = by0 - rmax, hy = by1 + rmax, lz = bz0 - rmax, hz = bz1 + rmax;
         const int cx0 = __builtin_amdgcn_readfirstlane(grid_coord(lx, tp.g.ox, tp.g.inv_c, tp.g.nx));
         const int cx1 = __builtin_amdgcn_readfirstlane(grid_coord(hx, tp.g.ox, tp.g.inv_c, tp.g.nx));
