@@ -236,8 +236,17 @@ __global__ void k_sat_axis(uint32_t* __restrict__ t, int nx, int ny, int nz, int
     if (axis == 0) { base = (size_t)i * nx; stride = 1; len = nx; }                                    // i = z*ny + y
     else if (axis == 1) { base = (size_t)(i / nx) * nx * ny + (size_t)(i % nx); stride = (size_t)nx; len = ny; }  // i = z*nx + x
     else { base = (size_t)i; stride = (size_t)nx * ny; len = nz; }                                     // i = y*nx + x
+    // (a thread's line is a chain of dependent additions, not of dependent loads: 16 elements are in flight at a time)
     uint32_t run = 0;
-    for (int k = 0; k < len; k++) { run += t[base + k * stride]; t[base + k * stride] = run; }
+    for (int k = 0; k < len; k += 16) {
+        uint32_t v[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) v[j] = k + j < len ? t[base + (size_t)(k + j) * stride] : 0u;
+#pragma unroll
+        for (int j = 0; j < 16; j++) { run += v[j]; v[j] = run; }
+#pragma unroll
+        for (int j = 0; j < 16; j++) if (k + j < len) t[base + (size_t)(k + j) * stride] = v[j];
+    }
 }
 // records in cells [x0..x1] x [y0..y1] x [z0..z1]; lanes 0..7 fetch one corner each (wave-uniform result)
 __device__ __forceinline__ unsigned int sat_box(const uint32_t* __restrict__ sat, int nx, int ny, int x0, int x1, int y0, int y1, int z0, int z1, int lane)
