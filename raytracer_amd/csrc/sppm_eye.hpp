@@ -110,7 +110,10 @@ template <class RNG, bool COMMIT, int GRID>
 __device__ __forceinline__ bool eye_path_step(const DevScene& sc, const EyeParams& ep, const HpArrays& hp, const HpArrays& out, EyeState<RNG>& e, uint32_t& rays)
 {
     const int P = ep.W * ep.H;
-    const int index = e.index;
+    // (opaque to the compiler: with a loop-invariant index it computes the ~25 store addresses of a pixel once, ahead of
+    // the path loop, and keeps them in 50 vector registers -- of which this kernel, at 128, then spills twice as many)
+    int index = e.index;
+    asm volatile("" : "+v"(index));
     e.depth++;
     Hit is;
     rays++;
@@ -192,7 +195,8 @@ __device__ __forceinline__ void eye_pixel_end(const EyeParams& ep, const HpArray
         // still reads `hp`): the direct term, the valid flag, and -- where this pass stored no hitpoint -- the
         // hitpoint the pixel already had (the reference overwrites a pixel's hitpoint only on a diffuse hit)
         const int P = ep.W * ep.H;
-        const int index = e.index;
+        int index = e.index;
+        asm volatile("" : "+v"(index));  // (see eye_path_step)
         out.ld[index] = e.ld.x; out.ld[P + index] = e.ld.y; out.ld[2 * P + index] = e.ld.z;
         out.valid[index] = e.valid;
         if (!e.wrote && e.valid) {
