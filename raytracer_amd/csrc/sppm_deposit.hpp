@@ -514,10 +514,12 @@ __global__ void __launch_bounds__(256) DEP_ATTR k_deposit_tiles(HpArrays hp, Rec
 #pragma unroll
     for (int h = 0; h < DEP_H; h++) {
         if (am[h] > 0) {
-            atomicAdd((unsigned long long*)hp.dep + t.p[h], (unsigned long long)ax[h]);
-            atomicAdd((unsigned long long*)hp.dep + (size_t)P + t.p[h], (unsigned long long)ay[h]);
-            atomicAdd((unsigned long long*)hp.dep + 2 * (size_t)P + t.p[h], (unsigned long long)az[h]);
-            atomicAdd((unsigned long long*)hp.dep + 3 * (size_t)P + t.p[h], (unsigned long long)am[h]);
+            int pi = t.p[h];
+            asm volatile("" : "+v"(pi));  // (the four addresses are formed here, not kept in registers through the item's loops)
+            atomicAdd((unsigned long long*)hp.dep + pi, (unsigned long long)ax[h]);
+            atomicAdd((unsigned long long*)hp.dep + (size_t)P + pi, (unsigned long long)ay[h]);
+            atomicAdd((unsigned long long*)hp.dep + 2 * (size_t)P + pi, (unsigned long long)az[h]);
+            atomicAdd((unsigned long long*)hp.dep + 3 * (size_t)P + pi, (unsigned long long)am[h]);
         }
         c_acc += (unsigned int)am[h];
     }

@@ -46,8 +46,10 @@ struct TileParams {
 // grid coordinate of x, clamped to [0, n-1]; monotone in x, so an interval maps to an index range
 __device__ __forceinline__ int grid_coord(double x, double o, double inv_c, int n)
 {
-    const double f = floor((x - o) * inv_c);
-    return f < 0.0 ? 0 : (f > (double)(n - 1) ? n - 1 : (int)f);
+    // (clamped as an integer: a `(double)(n - 1)` per axis is a wave-uniform value the compiler keeps in vector registers)
+    const double f = fmin(fmax(floor((x - o) * inv_c), 0.0), 2147483000.0);
+    const int i = (int)f;
+    return i > n - 1 ? n - 1 : i;
 }
 
 __device__ __forceinline__ int tile_of_pixel(int p, int W, int tiles_x) { return ((p / W) >> 3) * tiles_x + ((p % W) >> 3); }
@@ -652,8 +654,10 @@ __global__ void __launch_bounds__(256) GATHER_WAVES_ATTR k_gather_tiles(HpArrays
     }
     }  // clusters
     if (live) {
-        hp.r2[p] = r2; hp.n[p] = n;
-        hp.flux[p] = acc.x; hp.flux[P + p] = acc.y; hp.flux[2 * P + p] = acc.z;
+        int pi = p;
+        asm volatile("" : "+v"(pi));  // (the five addresses are formed here, not kept in registers through the item's loops)
+        hp.r2[pi] = r2; hp.n[pi] = n;
+        hp.flux[pi] = acc.x; hp.flux[P + pi] = acc.y; hp.flux[2 * P + pi] = acc.z;
     }
     for (int off = 32; off > 0; off >>= 1) c_acc += __shfl_down(c_acc, off);
     if (lane == 0) {
