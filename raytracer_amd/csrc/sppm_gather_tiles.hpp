@@ -409,8 +409,13 @@ __global__ void __launch_bounds__(256) GATHER_WAVES_ATTR k_gather_tiles(HpArrays
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int P = hp.P;
     const double BIG = 1e300;
+#ifdef GT_PIN
+    const double thr = pin_scalar_d(tp.gather_r2 * 0.01);
+    const double band_rel = pin_scalar_d(1e-9 + 8e-15 / thr);
+#else
     const double thr = tp.gather_r2 * 0.01;
     const double band_rel = 1e-9 + 8e-15 / thr;
+#endif
     // Persistent wavefronts: wave w starts with item w (thousands of waves asking one counter at the same
     // moment would queue up for a millisecond), then each takes the next item of the ordered list until the
     // list is empty (q[0] = number of items, q[1] = queue head beyond the first gridDim.x*4; every wave
