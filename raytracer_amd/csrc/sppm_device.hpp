@@ -118,10 +118,18 @@ __device__ __forceinline__ unsigned int mbcnt64(unsigned long long m)
 // folded away and the value stays in vector registers; this one it cannot see through.)
 __device__ __forceinline__ double pin_scalar_d(double v)
 {
+#ifdef PIN_RAW_ASM  // the first form, WRONG: kept only to reproduce DESIGN.md section 10 ("A pin that was wrong")
     int lo, hi;
     asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(lo) : "v"(__double2loint(v)));
     asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(hi) : "v"(__double2hiint(v)));
     return __hiloint2double(hi, lo);
+#else
+    // (the value passes through an empty asm, so the compiler no longer knows it is uniform and cannot fold the
+    // readfirstlane away; the instruction itself is the compiler's, with its hazard handling)
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    asm volatile("" : "+v"(lo), "+v"(hi));
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(hi), __builtin_amdgcn_readfirstlane(lo));
+#endif
 }
 // min / max over the wavefront by data-parallel primitives (DPP) instead of LDS permutes: four shifts within each row of
 // 16 lanes, then the rows' last lanes broadcast to the rows after them; lane 63 ends up with the result.  (A lane whose
