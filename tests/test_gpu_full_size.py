@@ -57,6 +57,27 @@ def test_config5_4k_10k_spheres_properties():
     _same(outs[1][1], img, "run-to-run image")
 
 
+def test_config5_4k_10k_spheres_per_pass_rule_run_to_run():
+    """the same scene under the per-pass rule: two renders of three passes agree in every bit of the hitpoint state (this
+    kind of test is what caught the raw-asm register pin of DESIGN.md section 10 in the ordered gather)"""
+    W, H, M = 3840, 2160, 1_000_000
+    table = scene.synthetic_spheres(10000)
+    outs = []
+    for _ in range(2):
+        ctx = sppm.SppmContext(sppm.make_config(W, H, photons_per_pass=M, update_rule=1), table)
+        for i in range(3):
+            ctx.eye_pass(i)
+            ctx.photon_pass(i, M)
+            ctx.end_pass()
+        ctx.check()
+        outs.append((ctx.hitpoints(), ctx.resolve(2, M).cpu().numpy(), ctx.counters()))
+        ctx.close()
+    assert outs[0][2]["updates"] == outs[1][2]["updates"] > 0
+    for k in ("valid", "obj", "r2", "flux", "ld"):
+        _same(outs[1][0][k], outs[0][0][k], f"run-to-run {k}")
+    _same(outs[1][1], outs[0][1], "run-to-run image")
+
+
 def test_config3_per_pass_rule_rank_shares_sum_to_the_pass():
     """north_star's split at full size: a pass of 8M photons at 1080p; every one of 8 'ranks' (one context, one after
     the other) deposits photons [r M/8, (r+1) M/8) into all hitpoints; the integer sum of the eight deposit arrays
