@@ -121,6 +121,9 @@ __global__ void __launch_bounds__(256) k_deposit_plan(HpArrays hp, const uint32_
                                                       unsigned long long* __restrict__ raw, uint8_t* __restrict__ n_pieces, uint32_t* __restrict__ est,
                                                       unsigned int* __restrict__ q)
 {
+    // (between two gathers the next gather waits for this kernel while the eye pass of the pass after runs beside it:
+    // its wavefronts go first where they share a SIMD)
+    __builtin_amdgcn_s_setprio(3);
     // (the item queue of the batch before is done with: cleared here, ahead of the kernels that count into it)
     if (blockIdx.x == 0 && threadIdx.x < 2 + ITEM_CLASSES) q[threadIdx.x] = 0u;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -572,6 +575,7 @@ __global__ void k_end_pass(HpArrays hp, DevScene sc, Own own, double alpha, doub
 __global__ void k_end_pass_resolve(HpArrays hp, DevScene sc, Own own, double alpha, double fx_inv, int32_t* __restrict__ err, int pass, int64_t photon_num,
                                    double* __restrict__ image)
 {
+    __builtin_amdgcn_s_setprio(3);  // (as k_deposit_plan: the next gather waits for it)
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     const size_t P = (size_t)hp.P;
     if (p >= hp.P) return;
