@@ -117,6 +117,46 @@ def run_ppm(tag, w, h, photons, traced, r2, k, seed_eye, seed_photon, supersampl
         print(f"wrote {path}: {os.path.getsize(path) / 1024:.0f} KiB, {len(hp_i)} hitpoints")
 
 
+def run_pp(tag, w, h, photons, passes, traced, r2, k, seed_eye, seed_photon, layout, stride):
+    """The per-pass rule: src/stochastic_ppm.h (namespace sppm_miss) through oracle/ref_driver_pp.cpp.
+    r2 <= 0: the search radius is the running maximum of the hitpoint radii (:577-581)."""
+    exe = os.path.join(ORACLE, "_ref", f"ref_driver_pp_{w}x{h}")
+    with tempfile.TemporaryDirectory() as d:
+        subprocess.check_call([exe, d, str(photons), str(passes), str(traced), repr(float(r2)), str(k), str(seed_eye), str(seed_photon), str(layout)])
+        P = w * h
+        out = dict(meta=np.array([w, h, photons, passes, traced, k, seed_eye, seed_photon, layout], np.int64), stride=np.array([stride]))
+        for i in range(passes):
+            hp_i = rd(d, f"eye_hp_i_pass{i}.bin", np.int32).reshape(P, 2)
+            hp_f = rd(d, f"eye_hp_f_pass{i}.bin", np.float64).reshape(P, 10)
+            ld = rd(d, f"eye_ld_pass{i}.bin", np.float64).reshape(P, 3)
+            dep_f = rd(d, f"dep_f_pass{i}.bin", np.float64).reshape(P, 3)
+            st_f = rd(d, f"state_f_pass{i}.bin", np.float64).reshape(P, 5)
+            img = rd(d, f"image_pass{i}.bin", np.float64).reshape(P, 3)
+            out[f"eye_words_pass{i}"] = rd(d, f"eye_words_pass{i}.bin", np.uint64)
+            if layout == 1:
+                out[f"stream_words_pass{i}"] = rd(d, f"stream_words_pass{i}.bin", np.uint64)
+            out[f"search_r2_pass{i}"] = rd(d, f"search_r2_pass{i}.bin", np.float64)
+            out[f"hp_valid_pass{i}"] = hp_i[:, 0].astype(np.int8)
+            out[f"hp_obj_pass{i}"] = hp_i[:, 1].astype(np.int8)
+            out[f"dep_m_pass{i}"] = rd(d, f"dep_m_pass{i}.bin", np.int32)     # M of every hitpoint, before the update
+            out[f"state_n_pass{i}"] = st_f[:, 0].copy()                       # N (a double under this rule) and r^2 of EVERY hitpoint
+            out[f"state_r2_pass{i}"] = st_f[:, 1].copy()
+            out[f"sums_pass{i}"] = np.array([hp_f.sum(), ld.sum(), dep_f.sum(), st_f.sum(), img.sum()])
+            out[f"hp_f_pass{i}"] = hp_f[::stride]
+            out[f"ld_pass{i}"] = ld[::stride]
+            out[f"dep_f_pass{i}"] = dep_f[::stride]                          # the double sums of :452-454
+            out[f"tau_pass{i}"] = st_f[::stride, 2:]
+            out[f"image_pass{i}"] = img[::stride]
+            out[f"ph_words_pass{i}"] = rd(d, f"ph_words_pass{i}.bin", np.int32)
+            out[f"ph_acc_off_pass{i}"] = rd(d, f"ph_acc_off_pass{i}.bin", np.int32)
+            out[f"ph_acc_pix_pass{i}"] = rd(d, f"ph_acc_pix_pass{i}.bin", np.int32)
+        out["final_hdr"] = np.frombuffer(open(os.path.join(d, "final.hdr"), "rb").read(), np.uint8)
+        out["final_ppm_sha256"] = np.frombuffer(hashlib.sha256(open(os.path.join(d, "final.ppm"), "rb").read()).digest(), np.uint8)
+        path = os.path.join(HERE, f"ref_pp_{tag}.npz")
+        np.savez_compressed(path, **out)
+        print(f"wrote {path}: {os.path.getsize(path) / 1024:.0f} KiB")
+
+
 def main():
     if not os.path.isdir("/root/reference/src"):
         sys.exit("the reference is not present here; fixtures can only be regenerated in the build container")
@@ -138,6 +178,13 @@ def main():
     # tag, W, H, photons, per-photon-traced, search r^2 (= InitialRadius, main.cpp:76-77), K cap, seeds, supersamples
     run_ppm("64x48", 64, 48, 20000, 4096, 25.0, 100000, 1000, 2000, 1)
     run_ppm("48x36_ss2_r5", 48, 36, 30000, 2048, 5.0, 100000, 31, 77, 2)
+    # the per-pass rule (src/stochastic_ppm.h): tag, W, H, photons/pass, passes, per-photon-traced, search r^2 (0 = running
+    # max of the hitpoint radii), K cap, seeds, stream layout (0 = sppm2's streams, 1 = render()'s own), stride
+    run_pp("64x48", 64, 48, 20000, 3, 4096, 0.0, 100000, 1000, 2000, 0, 1)
+    run_pp("64x48_l1", 64, 48, 20000, 2, 1024, 0.0, 100000, 31, 77, 1, 1)
+    run_pp("320x240", 320, 240, 100000, 2, 1024, 0.0, 100000, 1000, 2000, 0, 16)
+    run_pp("64x48_k8", 64, 48, 20000, 2, 2048, 0.0, 8, 31, 77, 0, 1)      # a BINDING K cap (:425-427 pass K to the same search)
+    run_pp("320x240_k100", 320, 240, 50000, 2, 512, 0.0, 100, 1000, 2000, 0, 16)
 
 
 if __name__ == "__main__":

@@ -26,7 +26,8 @@ class OrcParams(C.Structure):
                 ("sampler", C.c_int32), ("math", C.c_int32), ("rule", C.c_int32), ("double_nee", C.c_int32),
                 ("seed_eye", C.c_uint32), ("seed_photon", C.c_uint32),
                 ("photons_per_pass", C.c_int64),
-                ("camera_model", C.c_int32), ("seed_lens", C.c_uint32), ("aperture", C.c_double), ("focus_dist", C.c_double)]
+                ("camera_model", C.c_int32), ("seed_lens", C.c_uint32), ("aperture", C.c_double), ("focus_dist", C.c_double),
+                ("tracer", C.c_int32), ("accum", C.c_int32), ("stream_layout", C.c_int32), ("pad2", C.c_int32)]
 
 
 class OrcTap(C.Structure):
@@ -60,6 +61,8 @@ def lib():
     L.orc_get_deposits.argtypes = [C.c_void_p, C.c_void_p]
     L.orc_fixed_scale.restype = C.c_double
     L.orc_fixed_scale.argtypes = [C.c_void_p]
+    L.orc_get_deposits_d.argtypes = [C.c_void_p, C.c_void_p]
+    L.orc_get_nd.argtypes = [C.c_void_p, C.c_void_p]
     L.orc_photon_pass_mt.restype = C.c_int
     L.orc_photon_pass_mt.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_int, C.POINTER(C.c_double)]
     L.orc_max_threads.restype = C.c_int
@@ -105,7 +108,8 @@ def make_spheres(table):
 def make_params(width, height, *, samples=1, supersamples=1, cam_pos=(50.0, 52.0, 220.0), cam_dir=None,
                 cam_up=(0.0, 1.0, 0.0), screen_height=30.0, screen_dist=40.0, alpha=0.7, initial_radius2=25.0,
                 gather_radius2=25.0, gather_max=1 << 40, sampler=1, math=1, rule=0, double_nee=1,
-                seed_eye=1000, seed_photon=2000, photons_per_pass=0, camera_model=0, aperture=4.0, focus_dist=180.0, seed_lens=3000):
+                seed_eye=1000, seed_photon=2000, photons_per_pass=0, camera_model=0, aperture=4.0, focus_dist=180.0, seed_lens=3000,
+                tracer=0, accum=0, stream_layout=0):
     p = OrcParams()
     p.width, p.height, p.samples, p.supersamples = width, height, samples, supersamples
     if cam_dir is None:
@@ -123,6 +127,8 @@ def make_params(width, height, *, samples=1, supersamples=1, cam_pos=(50.0, 52.0
     p.seed_eye, p.seed_photon = seed_eye, seed_photon
     p.photons_per_pass = photons_per_pass
     p.camera_model, p.seed_lens, p.aperture, p.focus_dist = camera_model, seed_lens, aperture, focus_dist
+    # tracer 1 / accum 1 / stream_layout 1: src/stochastic_ppm.h as shipped (oracle/sppm_oracle.c, "Modes")
+    p.tracer, p.accum, p.stream_layout = tracer, accum, stream_layout
     return p
 
 
@@ -196,6 +202,18 @@ class Oracle:
         d = np.zeros((self.P, 4), np.int64)
         flag = self.L.orc_get_deposits(self.h, _p(d))
         return d, flag
+
+    def deposits_double(self):
+        """rule 1 with accum=1: the pass's double sums so far (accumulated_flux of stochastic_ppm.h:453), [P][3]"""
+        f = np.zeros((self.P, 3))
+        self.L.orc_get_deposits_d(self.h, _p(f))
+        return f
+
+    def state_nd(self):
+        """rule 1: N of every hitpoint as a double"""
+        nd = np.zeros(self.P)
+        self.L.orc_get_nd(self.h, _p(nd))
+        return nd
 
     def fixed_scale(self):
         return self.L.orc_fixed_scale(self.h)
