@@ -120,6 +120,12 @@ typedef struct sppm_config {
                                 sampler 1 seeds the one sequential mt19937 with it */
     double aperture;         /* lens diameter (lens_radius = aperture * 0.5, src/cameras.h:117) */
     double focus_dist;       /* distance of the plane in focus along camera_dir (src/cameras.h:133) */
+    int32_t tracer_variant;  /* 0: create_photon of the live src/sppm2.h:317-525 -- default, under either update rule.
+                                1: create_photon of src/stochastic_ppm.h:371-572 AS SHIPPED: no two discarded draws
+                                   (:377 against src/sppm2.h:322-324) and every diffuse bounce samples about the light's
+                                   emission basis (:482-483 use u, v, w of :382-393 where diffuse_u/v/w were meant).
+                                   For reproducing runs of that compiled file (tests/golden/ref_pp_*.npz); sampler 1 only. */
+    int32_t pad2_;
 } sppm_config;
 
 typedef struct sppm_ctx sppm_ctx;

@@ -33,7 +33,8 @@ class SppmConfig(C.Structure):
                 ("photons_per_pass", C.c_int64),
                 ("tile_first", C.c_int32), ("tile_stride", C.c_int32),
                 ("check_gather_max", C.c_int32), ("sampler", C.c_int32), ("ownership", C.c_int32), ("algorithm", C.c_int32),
-                ("camera_model", C.c_int32), ("seed_lens", C.c_uint32), ("aperture", C.c_double), ("focus_dist", C.c_double)]
+                ("camera_model", C.c_int32), ("seed_lens", C.c_uint32), ("aperture", C.c_double), ("focus_dist", C.c_double),
+                ("tracer_variant", C.c_int32), ("pad2_", C.c_int32)]
 
 
 _LIB = None

@@ -31,6 +31,7 @@
 #include <random>
 #include <string>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "sppm_device.hpp"
@@ -366,6 +367,8 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
     if (cfg->update_rule != 0 && cfg->update_rule != 1) return fail(SPPM_ERR_INVALID, "sppm_create: update_rule must be 0 or 1");
     if (cfg->ownership != 0 && cfg->ownership != 1) return fail(SPPM_ERR_INVALID, "sppm_create: ownership must be 0 (screen tiles) or 1 (ranges of the hitpoints' Morton order)");
     if (cfg->sampler != 0 && cfg->sampler != 1) return fail(SPPM_ERR_INVALID, "sppm_create: sampler must be 0 (XorShift streams) or 1 (reference mt19937 stream)");
+    if (cfg->tracer_variant != 0 && cfg->tracer_variant != 1) return fail(SPPM_ERR_INVALID, "sppm_create: tracer_variant must be 0 (src/sppm2.h) or 1 (src/stochastic_ppm.h as shipped)");
+    if (cfg->tracer_variant == 1 && (cfg->sampler != 1 || cfg->algorithm != 0)) return fail(SPPM_ERR_INVALID, "sppm_create: tracer_variant 1 reproduces runs of the compiled src/stochastic_ppm.h and needs sampler 1, algorithm 0");
     if (cfg->algorithm != 0 && cfg->algorithm != 1) return fail(SPPM_ERR_INVALID, "sppm_create: algorithm must be 0 (sppm2.h) or 1 (progressive_photonmapping.h)");
     if (cfg->algorithm == 1 && (cfg->update_rule != 0 || (cfg->tile_stride > 1 && cfg->ownership != 1)))
         return fail(SPPM_ERR_INVALID, "sppm_create: classic progressive photon mapping runs with update_rule 0; over several ranks its hitpoint list is shared out by ownership 1 (ranges of the Morton order)");
@@ -809,7 +812,7 @@ static int prepare_photon_stream(sppm_ctx* c, int32_t pass, int64_t count)
         TraceParams tp;
         memset(&tp, 0, sizeof tp);
         tp.pass = pass; tp.first = 0; tp.count = len; tp.photons_per_pass = c->cfg.photons_per_pass; tp.seed_photon = c->cfg.seed_photon;
-        tp.flux_scale = c->flux_scale; tp.rec_cap = 0; tp.u = c->d_u_ph; tp.u_len = len; tp.start = nullptr; tp.consumed = c->d_ph_consumed; tp.ppm = c->algo;
+        tp.flux_scale = c->flux_scale; tp.rec_cap = 0; tp.u = c->d_u_ph; tp.u_len = len; tp.start = nullptr; tp.consumed = c->d_ph_consumed; tp.ppm = c->algo; tp.miss = c->cfg.tracer_variant;
         const int blocks = (int)std::min<int64_t>(nblk(len, 256), 256 * 4);
         if (c->dscene.n_cells) hipLaunchKernelGGL((k_photon_trace<2, 1>), dim3(blocks), dim3(256), scene_lds(c), st, scene_of(c), tp, c->rec_buf[c->cur], c->d_rec_count_buf[c->cur],
                            c->d_trace_next_buf[c->cur], c->d_counters, c->d_err);
@@ -993,7 +996,7 @@ static int trace_into(sppm_ctx* c, int b, int32_t pass, int64_t first, int64_t c
     const int trace_blocks = (int)std::min<int64_t>(nblk(count, 256), env_i64("SPPM_TRACE_BLOCKS", c->dscene.n_cells ? 256 * 4 : 128));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->timing) { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventRecord(e0, st)); }
-    tp.u = nullptr; tp.u_len = 0; tp.start = nullptr; tp.consumed = nullptr; tp.ppm = c->algo;
+    tp.u = nullptr; tp.u_len = 0; tp.start = nullptr; tp.consumed = nullptr; tp.ppm = c->algo; tp.miss = c->cfg.tracer_variant;
     if (c->sampler == 1) {
         if (c->stream_pass != pass) return fail(SPPM_ERR_STATE, "reference-stream mode: the pass's stream offsets are made by sppm_photon_pass(pass, 0, photons)");
         tp.u = c->d_u_ph; tp.u_len = c->stream_len; tp.start = c->d_ph_start;

@@ -11,6 +11,10 @@ struct TraceParams {
     // hit deposits too, and the flux that reaches a hitpoint is multiply(obj.color, current_flux) of the PHOTON's
     // surface: the record stores that product
     int ppm;
+    // reference-stream mode only: 1 = create_photon of src/stochastic_ppm.h:371-572 AS SHIPPED instead of the live
+    // src/sppm2.h:317-525 -- no two discarded draws (:377), and a diffuse bounce samples about the LIGHT's emission
+    // basis (:482-483 use u, v, w of :382-393).  Exists to reproduce the compiled file's runs (tests/golden/ref_pp_*)
+    int miss;
 };
 struct RecArrays { uint64_t* key; double* f; int64_t cap; };  // f[9][cap]
 
@@ -26,7 +30,7 @@ struct RecArrays { uint64_t* key; double* f; int64_t cap; };  // f[9][cap]
 // MODE 2: "photon" i is a path started at stream offset i; no records, consumed[i] = draws it used.
 //         Following consumed[] from offset 0 (k_photon_chain) gives every real photon's start offset.
 // MODE 1: photon i reads the stream from start[i]; records as in mode 0.
-template <class RNG> struct PhotonState { RNG rng; d3 org, dir, flux; int depth; int64_t index; };
+template <class RNG> struct PhotonState { RNG rng; d3 org, dir, flux; int depth; int64_t index; d3 lw; /* emission normal, read only when tp.miss */ };
 struct Deposit { bool want; unsigned long long key; d3 pos, nrm, flux; };
 #define STREAM_OVER 0xFFFFFFFFu
 
@@ -36,7 +40,9 @@ __device__ __forceinline__ void photon_emit(const DevScene& sc, const TraceParam
     ps.index = i;
     if constexpr (MODE == 0) ps.rng = make_stream(tp.seed_photon, (uint64_t)tp.pass * (uint64_t)tp.photons_per_pass + (uint64_t)i);
     else { ps.rng.u = tp.u; ps.rng.end = tp.u_len; ps.rng.pos = MODE == 1 ? (int64_t)tp.start[i] : i; }
-    (void)ps.rng.next01(); (void)ps.rng.next01();  // two draws computed and discarded, src/sppm2.h:322-324
+    bool miss = false;
+    if constexpr (MODE != 0) miss = tp.miss != 0;
+    if (!miss) { (void)ps.rng.next01(); (void)ps.rng.next01(); }  // two draws computed and discarded, src/sppm2.h:322-324
     const double r1 = 2 * SPPM_PI * ps.rng.next01();
     const double r2 = 1.0 - 2.0 * ps.rng.next01();
     const double r3 = 1.0 - r2 * r2;
@@ -48,6 +54,7 @@ __device__ __forceinline__ void photon_emit(const DevScene& sc, const TraceParam
     d3 u, v;
     basis(w, u, v);
     ps.org = source_pos;
+    if constexpr (MODE != 0) ps.lw = w;
     ps.dir = cosine_sampling(w, u, v, ps.rng);
     ps.flux = ld3(sc.sp[0].emission) * 4.0 * tp.flux_scale;
     ps.depth = tp.ppm ? 0 : -1;
@@ -55,22 +62,22 @@ __device__ __forceinline__ void photon_emit(const DevScene& sc, const TraceParam
 
 // one iteration of the while loop of create_photon; returns false when the path ends
 template <class RNG>
-__device__ __forceinline__ bool photon_shade(const DevScene& sc, PhotonState<RNG>& ps, const Hit& is, Deposit& dep, int32_t* __restrict__ err, const bool ppm);
+__device__ __forceinline__ bool photon_shade(const DevScene& sc, PhotonState<RNG>& ps, const Hit& is, Deposit& dep, int32_t* __restrict__ err, const bool ppm, const bool miss);
 
 template <class RNG, int GRID>
-__device__ __forceinline__ bool photon_bounce(const DevScene& sc, PhotonState<RNG>& ps, Deposit& dep, int32_t* __restrict__ err, uint32_t& rays, const bool ppm)
+__device__ __forceinline__ bool photon_bounce(const DevScene& sc, PhotonState<RNG>& ps, Deposit& dep, int32_t* __restrict__ err, uint32_t& rays, const bool ppm, const bool miss)
 {
     if (ps.rng.stop()) return false;
     if (max3(ps.flux) <= 0.0) return false;
     Hit is;
     rays++;
     if (!intersect_scene<GRID>(sc, ps.org, ps.dir, is)) return false;
-    return photon_shade(sc, ps, is, dep, err, ppm);
+    return photon_shade(sc, ps, is, dep, err, ppm, miss);
 }
 
 // what create_photon does with a hit (src/sppm2.h:339-525): the record of a diffuse hit, roulette, the next direction
 template <class RNG>
-__device__ __forceinline__ bool photon_shade(const DevScene& sc, PhotonState<RNG>& ps, const Hit& is, Deposit& dep, int32_t* __restrict__ err, const bool ppm)
+__device__ __forceinline__ bool photon_shade(const DevScene& sc, PhotonState<RNG>& ps, const Hit& is, Deposit& dep, int32_t* __restrict__ err, const bool ppm, const bool miss)
 {
     const sppm_sphere* obj = &sc.sp[is.object_id];
     const d3 color = ld3(obj->color);
@@ -89,8 +96,15 @@ __device__ __forceinline__ bool photon_shade(const DevScene& sc, PhotonState<RNG
         const double prob = (color.x + color.y + color.z) / 3;
         if (!(prob > ps.rng.next01())) return false;
         d3 du, dv;
-        basis(on, du, dv);
-        ps.dir = cosine_sampling(on, du, dv, ps.rng);
+        bool about_light = false;
+        if constexpr (std::is_same<RNG, StreamRng>::value) about_light = miss;
+        if (about_light) {  // src/stochastic_ppm.h:468-483: diffuse_w/u/v are built and the light's w, u, v are used
+            basis(ps.lw, du, dv);
+            ps.dir = cosine_sampling(ps.lw, du, dv, ps.rng);
+        } else {
+            basis(on, du, dv);
+            ps.dir = cosine_sampling(on, du, dv, ps.rng);
+        }
         ps.org = is.position;
         ps.flux = had(ps.flux, color) / prob;
     } else if (type == SPPM_SPECULAR) {
@@ -135,7 +149,7 @@ __global__ void __launch_bounds__(256) TRACE_ATTR k_photon_trace(DevScene sc, Tr
     const int lane = threadIdx.x & 63;
     uint32_t rays = 0;
     PhotonState<RNG> ps;
-    ps.depth = 0; ps.index = 0; ps.org = mk(0, 0, 0); ps.dir = mk(0, 0, 1); ps.flux = mk(0, 0, 0);
+    ps.depth = 0; ps.index = 0; ps.org = mk(0, 0, 0); ps.dir = mk(0, 0, 1); ps.flux = mk(0, 0, 0); ps.lw = mk(0, 0, 1);
     if constexpr (MODE == 0) ps.rng.seed(1u); else { ps.rng.u = tp.u; ps.rng.pos = 0; ps.rng.end = tp.u_len; }
     bool active = false, exhausted = false;
     int64_t blk_lo = 0, blk_hi = 0;  // wave-uniform: the unassigned rest of this wave's current block
@@ -204,7 +218,7 @@ __global__ void __launch_bounds__(256) TRACE_ATTR k_photon_trace(DevScene sc, Tr
                         is.distance = my_best; is.object_id = my_id;
                         is.position = ps.org + ps.dir * my_best;
                         is.normal = normalize(is.position - ld3(sc.sp[my_id].position));
-                        active = photon_shade(sc, ps, is, dep, err, tp.ppm != 0);
+                        active = photon_shade(sc, ps, is, dep, err, tp.ppm != 0, MODE != 0 && tp.miss != 0);
                     }
                 }
                 if constexpr (MODE == 2)
@@ -214,7 +228,7 @@ __global__ void __launch_bounds__(256) TRACE_ATTR k_photon_trace(DevScene sc, Tr
             }
         } else
         if (active) {
-            active = photon_bounce<RNG, GRID>(sc, ps, dep, err, rays, tp.ppm != 0);
+            active = photon_bounce<RNG, GRID>(sc, ps, dep, err, rays, tp.ppm != 0, MODE != 0 && tp.miss != 0);
             if constexpr (MODE == 2)
                 if (!active) tp.consumed[ps.index] = ps.rng.stop() ? STREAM_OVER : (uint32_t)(ps.rng.pos - ps.index);
             if constexpr (MODE == 1)

@@ -28,7 +28,7 @@ def make_config(width, height, *, samples=1, supersamples=1, camera_position=sce
                 camera_up=scene.CAMERA_UP, screen_height=scene.SCREEN_HEIGHT, screen_dist=scene.SCREEN_DIST, alpha=0.7,
                 initial_radius2=25.0, gather_radius2=25.0, gather_max=1 << 40, update_rule=0, double_nee=1,
                 seed_eye=1000, seed_photon=2000, photons_per_pass=0, tile_first=0, tile_stride=0, sampler=0, ownership=0, algorithm=0,
-                camera_model=0, aperture=4.0, focus_dist=180.0, seed_lens=3000, check_gather_max=0):
+                camera_model=0, aperture=4.0, focus_dist=180.0, seed_lens=3000, check_gather_max=0, tracer_variant=0):
     cfg = capi.SppmConfig()
     cfg.width, cfg.height, cfg.samples, cfg.supersamples = width, height, samples, supersamples
     cfg.camera_position[:] = camera_position
@@ -47,6 +47,7 @@ def make_config(width, height, *, samples=1, supersamples=1, camera_position=sce
     # 0: the reference's K cap is enforced exactly whenever it could act (gather_max below the number of hitpoints);
     # 1: only count every query's candidates and report if any exceeds gather_max (brute force); 2: ignore the cap
     cfg.check_gather_max = check_gather_max
+    cfg.tracer_variant = tracer_variant  # 1 (with sampler 1): create_photon of src/stochastic_ppm.h as shipped
     cfg.algorithm = algorithm  # 0: sppm2.h (stochastic); 1: progressive_photonmapping.h (classic PPM, a list of hitpoints)
     cfg.ownership = ownership  # with tile_stride > 1 -- 0: 8x8 screen tiles round-robin; 1: ranges of the hitpoints' Morton order
     return cfg

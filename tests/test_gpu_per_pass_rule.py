@@ -1,10 +1,9 @@
 """update_rule 1, the per-pass (N, tau) rule of src/stochastic_ppm.h:721-741 with deposits in 64-bit fixed point
 (north_star's multi-GPU formulation: photons sharded, hitpoints replicated, ONE all-reduce of the deposits per pass).
 
-Parity for this rule is UNPINNED against the reference: that reference file is broken, so no fixture
-of the compiled reference covers it; the oracle restates its formula and the GPU must equal the oracle bit for bit.
-What IS pinned: the accepted (record, hitpoint) sets use the same search filter and acceptance test as the per-photon
-rule, whose sets are checked against the compiled reference's fixtures."""
+The oracle's restatement of this rule is pinned bit for bit by runs of the compiled src/stochastic_ppm.h
+(tests/test_oracle_vs_reference.py::test_per_pass_rule_pinned); here the GPU must equal the oracle bit for bit.
+tests/test_gpu_per_pass_reference.py holds the GPU against those compiled-reference runs directly."""
 import numpy as np
 import pytest
 
