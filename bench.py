@@ -277,6 +277,19 @@ def k_cap_enforced(width, height, photons, table, torch, passes=2):
                     "per photon hit; a fidelity mode, not the timed path"}
 
 
+def image_quality():
+    """Both update rules at equal pass and photon counts (320x240, 200k photons per pass, after 16 and 256 passes) against
+    the committed 65 536-pass render of the per-photon rule (tests/golden/converged_320x240_rule0.npz, made by
+    tools/render_converged.py with seeds of its own): which rule's image is closer.  The primary line may be the
+    per-pass rule only while its error is within 10 % of the per-photon rule's (tests/test_gpu_converged.py)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_gpu_converged import errors_vs_converged
+    e = errors_vs_converged()
+    return {"per_photon_rule": {str(k): v for k, v in e[0].items()}, "per_pass_rule": {str(k): v for k, v in e[1].items()},
+            "workload": "Cornell-box SPPM 320x240, 200000 photons/pass, relative RMSE after 16 and 256 passes against 65536 passes of the per-photon rule "
+                        "(different seeds); the long renders of the two rules differ by 0.0016 from each other"}
+
+
 # algorithmic work of the gather kernels (DESIGN.md section 5)
 PAIR_FLOP = 23.0      # FP64 operations of one (record, hitpoint) test: 3 sub, 5 |d|^2, 5 n.g, 5 g.d, 5 flatness with its band
 UPDATE_FLOP = {0: 24.0, 1: 0.0}   # per accepted update: rule 0 = shrink factor, 3 x (w c f / pi), (acc + add) g; rule 1 = integer adds only
@@ -407,6 +420,7 @@ def main():
     ap.add_argument("--photons", type=int, default=1_000_000, help="photons per pass per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-k-cap", action="store_true", help="skip the two passes with the reference's K cap enforced (N = 1)")
+    ap.add_argument("--no-converged", action="store_true", help="skip the 320x240 renders of both rules against the committed long render (N = 1)")
     ap.add_argument("--workload", choices=("sppm", "ppm"), default="sppm", help="sppm: BASELINE config 2/3 (the metric's workload); ppm: config 4, classic PPM")
     ap.add_argument("--spheres", type=int, default=0, help="sppm workload: N > 0 replaces the Cornell scene by raytracer_amd.scene.synthetic_spheres(N) "
                     "(BASELINE config 5: --spheres 10000 --width 3840 --height 2160); rays then walk a grid over the spheres")
@@ -480,6 +494,8 @@ def main():
         out["roofline"]["peak_measured"] = measured_fma_peak(torch)
         out["roofline"]["frac_of_measured_peak"] = out["roofline"]["achieved"] / out["roofline"]["peak_measured"]
         out["roofline"]["hbm_copy_GBps_measured"] = measured_stream_bandwidth(torch)
+        if world == 1 and not args.no_converged and args.spheres <= 0:
+            out["image_rel_rmse_vs_converged"] = image_quality()
         if world == 1 and not args.no_k_cap and args.spheres <= 0:
             out["k_cap"] = k_cap_enforced(args.width, args.height, args.photons, table, torch)
         if world == 1 and not args.no_cpu_baseline:

@@ -260,7 +260,7 @@ int sppm_download_hitpoint_pixels(sppm_ctx* ctx, int32_t* h_pix);
  * normal, weight; r2[P]; n[P]; flux[P][3]; ld[P][3]. */
 int sppm_download_hitpoints(sppm_ctx* ctx, int32_t* h_valid, int32_t* h_obj, double* h_hp_f, double* h_r2,
                             int32_t* h_n, double* h_flux, double* h_ld);
-/* Records currently in the buffer, sorted by key: key[n] (photon<<16 | depth<<1 | orient),
+/* Records currently in the buffer, sorted by key: key[n] (photon<<20 | depth<<1 | orient),
  * f[n][9] = position, geometric normal, flux.  Returns the count through n (call with NULL arrays
  * to size). */
 int sppm_download_records(sppm_ctx* ctx, uint64_t* h_key, double* h_f, int64_t* n);

@@ -144,7 +144,7 @@ __global__ void k_bin_count(RecArrays rec, const unsigned long long* __restrict_
         const int ix = grid_coord(rec.f[i], g.ox, g.inv_c, g.nx);
         const int iy = grid_coord(rec.f[rec.cap + i], g.oy, g.inv_c, g.ny);
         const int iz = grid_coord(rec.f[2 * rec.cap + i], g.oz, g.inv_c, g.nz);
-        int64_t slab = ((int64_t)(rec.key[i] >> 16) - g.first) / g.B;
+        int64_t slab = ((int64_t)(rec.key[i] >> KEY_SHIFT) - g.first) / g.B;
         if (slab < 0 || slab >= g.S) { err[3] = 1; slab = slab < 0 ? 0 : g.S - 1; }  // a record outside the declared photon range
         const uint32_t b = (uint32_t)slab * (uint32_t)g.ncells + (uint32_t)((iz * g.ny + iy) * g.nx + ix);
         rec_bucket[i] = b;
@@ -491,8 +491,8 @@ __global__ void __launch_bounds__(256) GATHER_WAVES_ATTR k_gather_tiles(HpArrays
         const int kx = cx1 - cx0 + 1, ky = cy1 - cy0 + 1, kz = cz1 - cz0 + 1;
         const int Ktot = kx * ky * kz;
         const uint32_t slab_base = (uint32_t)s * (uint32_t)tp.g.ncells;
-        const unsigned long long kend = (unsigned long long)(tp.g.first + (int64_t)(s + 1) * tp.g.B) << 16;
-        unsigned long long klo = (unsigned long long)(tp.g.first + (int64_t)s * tp.g.B) << 16;
+        const unsigned long long kend = (unsigned long long)(tp.g.first + (int64_t)(s + 1) * tp.g.B) << KEY_SHIFT;
+        unsigned long long klo = (unsigned long long)(tp.g.first + (int64_t)s * tp.g.B) << KEY_SHIFT;
         unsigned long long khi = kend;
         while (klo < kend) {
             // ---- collect the candidates with key in [klo, khi) inside the region into LDS (at most 64)

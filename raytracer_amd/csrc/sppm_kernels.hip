@@ -1957,7 +1957,7 @@ extern "C" int sppm_check(sppm_ctx* c)
     int rc = resolve_events(c);
     if (rc) return rc;
     if (err[0]) return fail(SPPM_ERR_OVERFLOW, "record buffer overflow: raise SPPM_RECORD_CAP or lower SPPM_BATCH_PHOTONS");
-    if (err[1]) return fail(SPPM_ERR_OVERFLOW, "a photon path exceeded 32767 bounces");
+    if (err[1]) return fail(SPPM_ERR_OVERFLOW, "a photon path exceeded 524287 bounces (the depth field of the record key)");
     if (err[2]) return fail(SPPM_ERR_OVERFLOW, "a photon hit had more than gather_max candidate hitpoints: the reference's K cap would have acted (check_gather_max = 1 only counts; 0 enforces the cap; sppm_counters [14] has the largest count)");
     if (err[3]) return fail(SPPM_ERR_STATE, "a record's photon index lies outside the range declared for the batch");
     if (err[4]) return fail(SPPM_ERR_OVERFLOW, "reference-stream mode: a path ran past the uploaded part of the stream");

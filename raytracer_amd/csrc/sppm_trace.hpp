@@ -17,6 +17,12 @@ struct TraceParams {
     int miss;
 };
 struct RecArrays { uint64_t* key; double* f; int64_t cap; };  // f[9][cap]
+// A record's key: photon << KEY_SHIFT | depth << 1 | orient -- key order is the reference's application order.  The depth
+// field holds 524 287 bounces: a path caught in total reflection inside the glass sphere loses 1 % of its flux per bounce
+// (colour 0.99) and the reference ends it when the flux underflows to zero (src/sppm2.h:355), after ~75 000 bounces, so
+// the field cannot overflow on the reference's scene (16 bits did: once in ~5 G photons a path passed 32 767).
+#define KEY_SHIFT 20
+#define KEY_MAX_DEPTH ((1 << (KEY_SHIFT - 1)) - 1)
 
 // create_photon, src/sppm2.h:317-525, with the kd search + update replaced by appending a photon-hit
 // record (diffuse hit, depth > 0).  Photon paths have very different lengths (the longest of 64 is
@@ -87,10 +93,10 @@ __device__ __forceinline__ bool photon_shade(const DevScene& sc, PhotonState<RNG
     ps.depth++;
     if (type == SPPM_DIFFUSE) {
         if (ps.depth > 0) {
-            if (ps.depth > 32767) { err[1] = 1; return false; }
+            if (ps.depth > KEY_MAX_DEPTH) { err[1] = 1; return false; }
             // the record is stored by the caller, where the whole wavefront has reconverged
             dep.want = true;
-            dep.key = ((uint64_t)ps.index << 16) | ((uint64_t)ps.depth << 1) | (flip ? 1ull : 0ull);
+            dep.key = ((uint64_t)ps.index << KEY_SHIFT) | ((uint64_t)ps.depth << 1) | (flip ? 1ull : 0ull);
             dep.pos = is.position; dep.nrm = is.normal; dep.flux = ppm ? had(color, ps.flux) : ps.flux;
         }
         const double prob = (color.x + color.y + color.z) / 3;

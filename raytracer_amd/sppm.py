@@ -13,6 +13,9 @@ import numpy as np
 from . import capi, scene
 
 
+KEY_SHIFT = 20  # a photon-hit record's key: photon << KEY_SHIFT | depth << 1 | orient (raytracer_amd/csrc/sppm_trace.hpp)
+
+
 def _sphere_array(table):
     arr = (capi.SppmSphere * len(table))()
     for s, (r, p, e, c, t) in zip(arr, table):

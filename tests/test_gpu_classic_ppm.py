@@ -72,7 +72,7 @@ def test_classic_ppm_matches_oracle_bit_for_bit(w, h, ss, r2, photons, monkeypat
     ctx.trace(0, 0, photons)
     key, f = ctx.download_records()
     tap = orc.photon_pass(0, photons, tap=True, acc_cap=60_000_000)
-    okey = (tap["rec_photon"].astype(np.uint64) << np.uint64(16)) | (tap["rec_depth"].astype(np.uint64) << np.uint64(1))
+    okey = (tap["rec_photon"].astype(np.uint64) << np.uint64(sppm.KEY_SHIFT)) | (tap["rec_depth"].astype(np.uint64) << np.uint64(1))
     okey |= (tap["rec_f"][:, 3:6] != tap["rec_f"][:, 6:9]).any(axis=1).astype(np.uint64)
     assert tap["rec_depth"].min() == 1, "photons deposit from their first hit on"
     _same(key, okey, "record keys")

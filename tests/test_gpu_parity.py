@@ -86,7 +86,7 @@ def test_passes_match_oracle_bit_for_bit(r2, passes):
         key, f = ctx.download_records()
         tap = orc.photon_pass(i, M, tap=True)
         n_records += len(tap["rec_photon"])
-        okey = (tap["rec_photon"].astype(np.uint64) << np.uint64(16)) | (tap["rec_depth"].astype(np.uint64) << np.uint64(1))
+        okey = (tap["rec_photon"].astype(np.uint64) << np.uint64(sppm.KEY_SHIFT)) | (tap["rec_depth"].astype(np.uint64) << np.uint64(1))
         flip = (tap["rec_f"][:, 3:6] != tap["rec_f"][:, 6:9]).any(axis=1)
         okey |= flip.astype(np.uint64)
         _same(key, okey, f"pass {i} record keys")

@@ -40,7 +40,7 @@ def test_per_pass_rule_matches_oracle(r2):
         akey, apix = ctx.accepted()
         ctx.accept_tap(0)
         tap = orc.photon_pass(i, M, tap=True, acc_cap=6_000_000)
-        okey = (tap["rec_photon"].astype(np.uint64) << np.uint64(16)) | (tap["rec_depth"].astype(np.uint64) << np.uint64(1))
+        okey = (tap["rec_photon"].astype(np.uint64) << np.uint64(sppm.KEY_SHIFT)) | (tap["rec_depth"].astype(np.uint64) << np.uint64(1))
         okey |= (tap["rec_f"][:, 3:6] != tap["rec_f"][:, 6:9]).any(axis=1).astype(np.uint64)
         ok = okey[tap["acc_rec"]]
         order = np.lexsort((tap["acc_pix"], ok))
