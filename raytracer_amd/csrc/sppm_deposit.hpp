@@ -117,43 +117,52 @@ __device__ __forceinline__ DepRegion dep_region(const DepTile& t, const bool (&i
 
 // One wavefront per tile: the clusters, the records in each cluster's region, and the cut of every region's records into at most DEP_MAX_CHUNKS chunks of ~chunk_records.  Tile k
 // writes its pieces to raw[k*64 ..] as (cost estimate << 32 | item) and their number (<= 64) to n_pieces[k].
+// Round 3: it also does what three more launches between two deposits used to do -- the tile's extent bin for the grid
+// statistics (k_tile_extent: the same hitpoints were loaded and reduced a second time there) and the clearing of the item
+// queue and of the statistics that k_items_count / k_items_place (below) fill in.
 __global__ void __launch_bounds__(256) k_deposit_plan(HpArrays hp, const uint32_t* __restrict__ cell_start, TileParams tp, int n_tiles, uint32_t chunk_records,
                                                       unsigned long long* __restrict__ raw, uint8_t* __restrict__ n_pieces, uint32_t* __restrict__ est,
-                                                      unsigned int* __restrict__ q)
+                                                      unsigned int* __restrict__ q, uint8_t* __restrict__ ext_bin, TileStats* __restrict__ st)
 {
     // (between two gathers the next gather waits for this kernel while the eye pass of the pass after runs beside it:
     // its wavefronts go first where they share a SIMD)
     __builtin_amdgcn_s_setprio(3);
-    // (the item queue of the batch before is done with: cleared here, ahead of the kernels that count into it)
-    if (blockIdx.x == 0 && threadIdx.x < 2 + ITEM_CLASSES) q[threadIdx.x] = 0u;
+    // (the item queue of the batch before is done with, and so are the statistics: cleared here, ahead of the kernels
+    // that count into them)
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < 2 + 2 * ITEM_CLASSES) q[threadIdx.x] = 0u;
+        if (threadIdx.x < 64) st->hist[threadIdx.x] = 0u;
+        if (threadIdx.x == 64) { st->live_tiles = 0u; st->pad = 0u; st->est_sum = 0ull; }
+    }
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int k = blockIdx.x * 4 + wv;
     if (k >= n_tiles) return;
     DepTile t;
-    if (!dep_load_tile(hp, tp, k, lane, t)) { if (lane == 0) { est[k] = 0; n_pieces[k] = 0; } return; }
+    if (!dep_load_tile(hp, tp, k, lane, t)) { if (lane == 0) { est[k] = 0; n_pieces[k] = 0; ext_bin[k] = 0; } return; }
     unsigned long long remaining[DEP_H];
 #pragma unroll
     for (int h = 0; h < DEP_H; h++) remaining[h] = ballot64(t.live[h]);
     int n_out = 0;
     unsigned int total = 0;
+    double tile_ext = -1.0;
     for (int c = 0; dep_any(remaining); c++) {
         bool inc[DEP_H];
         dep_next_cluster(remaining, c, t, lane, tp.cluster_d, inc);
         const DepRegion R = dep_region(t, inc, tp);
-        // the records in the region's cells, counted directly (one slab: a cell's count is a difference of two starts;
-        // a few hundred cells, 64 per trip -- cheaper than building a summed-area table over all cells for 8 lookups)
+        // a tile that is one cluster (nearly all are): its extent is this region's
+        if (c == 0 && !dep_any(remaining)) tile_ext = fmax(R.bx1 - R.bx0, fmax(R.by1 - R.by0, R.bz1 - R.bz0)) + 2.0 * R.rmax;
+        // the records in the region's cells, counted directly: one slab, and the cells of a row (x) are consecutive in the
+        // table, so a row's count is the difference of two starts -- one lane per (y, z) row, usually one trip
         const int kx = R.cx1 - R.cx0 + 1, ky = R.cy1 - R.cy0 + 1, kz = R.cz1 - R.cz0 + 1;
         const unsigned int cells = (unsigned int)(kx * ky * kz);
+        const int rows = ky * kz;
         unsigned int T = 0;
-        for (int qbase = 0; qbase < (int)cells; qbase += 64) {
-            const int qi = qbase + lane;
-            uint32_t cnt = 0;
-            if (qi < (int)cells) {
-                const int ix = R.cx0 + qi % kx, iy = R.cy0 + (qi / kx) % ky, iz = R.cz0 + qi / (kx * ky);
-                const uint32_t b = (uint32_t)((iz * tp.g.ny + iy) * tp.g.nx + ix);
-                cnt = cell_start[b + 1] - cell_start[b];
+        for (int rb = 0; rb < rows; rb += 64) {
+            const int rj = rb + lane;
+            if (rj < rows) {
+                const uint32_t b0 = (uint32_t)(((R.cz0 + rj / ky) * tp.g.ny + (R.cy0 + rj % ky)) * tp.g.nx + R.cx0);
+                T += cell_start[b0 + kx] - cell_start[b0];
             }
-            T += cnt;
         }
         for (int off = 32; off > 0; off >>= 1) T += __shfl_xor(T, off);
         T = (unsigned int)__builtin_amdgcn_readfirstlane((int)T);
@@ -169,13 +178,92 @@ __global__ void __launch_bounds__(256) k_deposit_plan(HpArrays hp, const uint32_
         n_out += cn;
         total += T + 16u + (cells >> 3);
     }
-    if (lane == 0) { est[k] = total; n_pieces[k] = (uint8_t)n_out; }
+    if (tile_ext < 0.0) {  // several clusters: the whole tile's box and largest radius, as k_tile_extent takes them
+        const double BIG = 1e300;
+        double lx = BIG, hx = -BIG, ly = BIG, hy = -BIG, lz = BIG, hz = -BIG, rr = 0.0;
+#pragma unroll
+        for (int h = 0; h < DEP_H; h++)
+            if (t.live[h]) {
+                lx = fmin(lx, t.x[h]); hx = fmax(hx, t.x[h]); ly = fmin(ly, t.y[h]); hy = fmax(hy, t.y[h]); lz = fmin(lz, t.z[h]); hz = fmax(hz, t.z[h]);
+                rr = fmax(rr, sqrt(fmin(t.r2[h], tp.gather_r2)));
+            }
+        tile_ext = fmax(wave_max_d(hx) - wave_min_d(lx), fmax(wave_max_d(hy) - wave_min_d(ly), wave_max_d(hz) - wave_min_d(lz))) + 2.0 * wave_max_d(rr);
+    }
+    if (lane == 0) {
+        est[k] = total; n_pieces[k] = (uint8_t)n_out;
+        int e;
+        frexp(tile_ext, &e);  // in [2^(e-1), 2^e)
+        e = e + 32;
+        e = e < 0 ? 0 : (e > 62 ? 62 : e);
+        ext_bin[k] = (uint8_t)(e + 1);
+    }
+}
+
+// The pieces by cost class, heaviest first (as k_items_hist / k_items_bases / k_items_scatter of sppm_gather_tiles.hpp, in
+// two launches instead of three, and with the grid statistics riding along).  q: [0] number of items, [1] the deposit
+// kernel's queue head, [2 + c] pieces of class c, [2 + ITEM_CLASSES + c] write cursor of class c; all cleared by
+// k_deposit_plan.
+// First launch: count the pieces per class and the tiles per extent bin.
+__global__ void __launch_bounds__(256) k_items_count(const unsigned long long* __restrict__ raw, const uint8_t* __restrict__ n_pieces, int n_tiles,
+                                                     unsigned int* __restrict__ q, const uint8_t* __restrict__ ext_bin, TileStats* __restrict__ st)
+{
+    __shared__ unsigned int h[ITEM_CLASSES], eh[64], live;
+    if (threadIdx.x < ITEM_CLASSES) h[threadIdx.x] = 0;
+    if (threadIdx.x < 64) eh[threadIdx.x] = 0;
+    if (threadIdx.x == 0) live = 0;
+    __syncthreads();
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = k < n_tiles ? n_pieces[k] : 0;
+    for (int j = 0; j < n; j++) atomicAdd(&h[item_class((unsigned int)(raw[(size_t)k * 64 + j] >> 32))], 1u);
+    const int b = k < n_tiles ? ext_bin[k] : 0;
+    if (b) { atomicAdd(&eh[b - 1], 1u); atomicAdd(&live, 1u); }
+    __syncthreads();
+    if (threadIdx.x < ITEM_CLASSES && h[threadIdx.x]) { atomicAdd(&q[2 + threadIdx.x], h[threadIdx.x]); atomicAdd(&q[0], h[threadIdx.x]); }
+    if (threadIdx.x < 64 && eh[threadIdx.x]) atomicAdd(&st->hist[threadIdx.x], eh[threadIdx.x]);
+    if (threadIdx.x == 0 && live) atomicAdd(&st->live_tiles, live);
+}
+// Second launch: every block derives the classes' bases from the counts (heaviest class first) and places its pieces;
+// block 0 also clears the record counter of the batch's buffer (its records are binned by now) and writes the host's
+// snapshot of the statistics (k_stat_snapshot).
+__global__ void __launch_bounds__(256) k_items_place(const unsigned long long* __restrict__ raw, const uint8_t* __restrict__ n_pieces, int n_tiles,
+                                                     unsigned int* __restrict__ q, uint32_t* __restrict__ items, unsigned long long* __restrict__ rec_count,
+                                                     const TileStats* __restrict__ st, const unsigned long long* __restrict__ bb,
+                                                     const unsigned long long* __restrict__ counters, StatSnapshot* __restrict__ out)
+{
+    __shared__ unsigned int h[ITEM_CLASSES], base[ITEM_CLASSES];
+    if (threadIdx.x < ITEM_CLASSES) h[threadIdx.x] = 0;
+    __syncthreads();
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = k < n_tiles ? n_pieces[k] : 0;
+    for (int j = 0; j < n; j++) atomicAdd(&h[item_class((unsigned int)(raw[(size_t)k * 64 + j] >> 32))], 1u);
+    __syncthreads();
+    if (threadIdx.x < ITEM_CLASSES) {
+        unsigned int before = 0;  // pieces of the heavier classes
+        for (int c = ITEM_CLASSES - 1; c > (int)threadIdx.x; c--) before += q[2 + c];
+        base[threadIdx.x] = before + (h[threadIdx.x] ? atomicAdd(&q[2 + ITEM_CLASSES + threadIdx.x], h[threadIdx.x]) : 0u);
+        h[threadIdx.x] = 0;
+    }
+    __syncthreads();
+    for (int j = 0; j < n; j++) {
+        const unsigned long long w = raw[(size_t)k * 64 + j];
+        const int c = item_class((unsigned int)(w >> 32));
+        items[base[c] + atomicAdd(&h[c], 1u)] = (uint32_t)w;
+    }
+    if (blockIdx.x == 0) {
+        const int t = threadIdx.x;
+        if (t == 0) *rec_count = 0ull;
+        if (t < 64) out->hs.hist[t] = st->hist[t];
+        if (t == 0) { out->hs.live_tiles = st->live_tiles; out->hs.pad = 0; out->hs.est_sum = st->est_sum; }
+        if (t < 6) out->bbq[t] = bb[t];
+        if (t < 24) out->cnt[t] = counters[t];
+    }
 }
 
 #ifndef DEP_WAVES
 #define DEP_WAVES (DEP_H == 1 ? 4 : 3)  // register budget: 512 / DEP_WAVES per lane
 #endif
 #define DEP_ATTR __attribute__((amdgpu_waves_per_eu(DEP_WAVES, DEP_WAVES)))
+#define DEP_FLUSH_ROWS 2048  // staged rows after which the double sums move to the 64-bit integers (2048 x 2^41 = 2^52)
 #define DEP_ROWS 64  // staged records per wavefront: one group of candidates at a time, processed while the next group's loads are in flight
 template <bool TAP, bool STAMPS = false>
 __global__ void __launch_bounds__(256) DEP_ATTR k_deposit_tiles(HpArrays hp, RecArrays rec, const uint32_t* __restrict__ cell_start, TileParams tp,
@@ -183,7 +271,7 @@ __global__ void __launch_bounds__(256) DEP_ATTR k_deposit_tiles(HpArrays hp, Rec
                                                        unsigned long long* __restrict__ counters, int32_t* __restrict__ err)
 {
     constexpr int ROW = TAP ? 11 : 10;
-    // a staged record of the full test: position, geometric normal, fixed-point flux (3 x int64 bits); of the distance-only
+    // a staged record of the full test: position, geometric normal, fixed-point flux (integer-valued doubles); of the distance-only
     // test: position about the cluster's centre, its square, flux, position; [ROW - 1: key bits]
     __shared__ double s_row[4][DEP_ROWS][ROW];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -256,13 +344,32 @@ __global__ void __launch_bounds__(256) DEP_ATTR k_deposit_tiles(HpArrays hp, Rec
     // value is farther than 1e-13 (relative; the dot products: absolute) from its bound, and a record for which any
     // hitpoint is closer than that is evaluated again with the reference's exact operation order (once in ~10^10 pairs).
     double lim_lo[DEP_H], lim_hi[DEP_H];
-    long long ax[DEP_H], ay[DEP_H], az[DEP_H];
+    // sums of the records' fixed-point flux, which k_grid_scatter stores as integer-valued doubles below 2^41 + 1: v_add_f64
+    // is exact while a sum stays below 2^53, so the sums move to the 64-bit atomics before DEP_FLUSH_ROWS rows are added
+    double ax[DEP_H], ay[DEP_H], az[DEP_H];
     int am[DEP_H];
+    unsigned int c_acc = 0, rows_unflushed = 0;
 #pragma unroll
     for (int h = 0; h < DEP_H; h++) {
         const double lim = fmin(t.r2[h], tp.gather_r2);  // a record is accepted at d2 < gather_r2 && d2 <= r2
         lim_lo[h] = inc[h] ? lim * (1.0 - 1e-13) : -1.0; lim_hi[h] = inc[h] ? lim * (1.0 + 1e-13) : -1.0;  // -1: never inside, never too close to call
-        ax[h] = ay[h] = az[h] = 0; am[h] = 0;
+        ax[h] = ay[h] = az[h] = 0.0; am[h] = 0;
+    }
+#define DEP_FLUSH()                                                                                                    \
+    {                                                                                                                  \
+        _Pragma("unroll") for (int h = 0; h < DEP_H; h++) {                                                            \
+            if (am[h] > 0) {                                                                                           \
+                int pi = t.p[h];                                                                                       \
+                asm volatile("" : "+v"(pi)); /* (the four addresses are formed here, not kept in registers through the loops) */ \
+                atomicAdd((unsigned long long*)hp.dep + pi, (unsigned long long)(long long)ax[h]);                     \
+                atomicAdd((unsigned long long*)hp.dep + (size_t)P + pi, (unsigned long long)(long long)ay[h]);         \
+                atomicAdd((unsigned long long*)hp.dep + 2 * (size_t)P + pi, (unsigned long long)(long long)az[h]);     \
+                atomicAdd((unsigned long long*)hp.dep + 3 * (size_t)P + pi, (unsigned long long)am[h]);                \
+            }                                                                                                          \
+            c_acc += (unsigned int)am[h];                                                                              \
+            ax[h] = ay[h] = az[h] = 0.0; am[h] = 0;                                                                    \
+        }                                                                                                              \
+        rows_unflushed = 0;                                                                                            \
     }
     // Whole-cluster bounds for the two tests that do not involve the radius (DEP_H == 1).  The 64 hitpoints of a cluster
     // lie within a fraction of a unit of each other, nearly always on one surface: for most staged records the normal
@@ -385,7 +492,7 @@ __global__ void __launch_bounds__(256) DEP_ATTR k_deposit_tiles(HpArrays hp, Rec
             const unsigned long long m_e = ballot64(in && easy), m_f = ballot64(in && !easy);
             if (in) {
                 double* row = s_row[wv][easy ? (int)mbcnt64(m_e) : DEP_ROWS - 1 - (int)mbcnt64(m_f)];
-                const double f6 = p6, f7 = p7, f8 = p8;  // fixed-point bits already (k_grid_scatter)
+                const double f6 = p6, f7 = p7, f8 = p8;  // fixed point already (k_grid_scatter): integer-valued doubles
                 if (easy) {
                     const double qx = p0 - bcx, qy = p1 - bcy, qz = p2 - bcz;
                     row[0] = qx; row[1] = qy; row[2] = qz; row[3] = fma(qz, qz, fma(qy, qy, qx * qx));
@@ -410,12 +517,14 @@ __global__ void __launch_bounds__(256) DEP_ATTR k_deposit_tiles(HpArrays hp, Rec
         __builtin_amdgcn_wave_barrier();
         c_sel += (unsigned int)sel_n; c_pairs += (unsigned long long)sel_n * R.n_inc; c_round++;
         const int ne_u = __builtin_amdgcn_readfirstlane(n_easy), nf_u = __builtin_amdgcn_readfirstlane(n_full);
+        if (rows_unflushed + (unsigned int)sel_n > DEP_FLUSH_ROWS) DEP_FLUSH()
+        rows_unflushed += (unsigned int)sel_n;
         // rows [0, n_easy): the normal and flatness tests pass for the whole cluster, the distance test alone decides.
         // Two records per trip (independent chains of LDS read -> three fused multiply-adds -> compares); a pair too
         // close to call (see E above) is left out here and only noted in `und` -- the loop carries no branch for it.
 #define DEP_TAKE(rowp)                                                                                                 \
         {                                                                                                              \
-            ax[0] += __double_as_longlong((rowp)[4]); ay[0] += __double_as_longlong((rowp)[5]); az[0] += __double_as_longlong((rowp)[6]); am[0]++; \
+            ax[0] += (rowp)[4]; ay[0] += (rowp)[5]; az[0] += (rowp)[6]; am[0]++;                                      \
             if (TAP) {                                                                                                 \
                 const unsigned long long ts = atomicAdd(tp.tap_n, 1ull);                                               \
                 if ((int64_t)ts < tp.tap_cap) { tp.tap_key[ts] = (unsigned long long)__double_as_longlong((rowp)[ROW - 1]); tp.tap_pix[ts] = t.p[0]; } \
@@ -494,7 +603,7 @@ __global__ void __launch_bounds__(256) DEP_ATTR k_deposit_tiles(HpArrays hp, Rec
 #pragma unroll
             for (int h = 0; h < DEP_H; h++) any_ok = any_ok || ok[h];
             if (any_ok) {
-                const long long fx = __double_as_longlong(row[6]), fy = __double_as_longlong(row[7]), fz = __double_as_longlong(row[8]);
+                const double fx = row[6], fy = row[7], fz = row[8];
 #pragma unroll
                 for (int h = 0; h < DEP_H; h++) {
                     if (ok[h]) {
@@ -513,19 +622,8 @@ __global__ void __launch_bounds__(256) DEP_ATTR k_deposit_tiles(HpArrays hp, Rec
     }
 #undef DEP_ISSUE
     const unsigned long long tf0 = DSTAMP();
-    unsigned int c_acc = 0;
-#pragma unroll
-    for (int h = 0; h < DEP_H; h++) {
-        if (am[h] > 0) {
-            int pi = t.p[h];
-            asm volatile("" : "+v"(pi));  // (the four addresses are formed here, not kept in registers through the item's loops)
-            atomicAdd((unsigned long long*)hp.dep + pi, (unsigned long long)ax[h]);
-            atomicAdd((unsigned long long*)hp.dep + (size_t)P + pi, (unsigned long long)ay[h]);
-            atomicAdd((unsigned long long*)hp.dep + 2 * (size_t)P + pi, (unsigned long long)az[h]);
-            atomicAdd((unsigned long long*)hp.dep + 3 * (size_t)P + pi, (unsigned long long)am[h]);
-        }
-        c_acc += (unsigned int)am[h];
-    }
+    DEP_FLUSH()
+#undef DEP_FLUSH
     for (int off = 32; off > 0; off >>= 1) c_acc += __shfl_down(c_acc, off);
     if (lane == 0) {
         if (c_pairs) atomicAdd(&counters[3], c_pairs);

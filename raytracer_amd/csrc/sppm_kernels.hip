@@ -47,6 +47,7 @@
 #include "sppm_exchange.hpp"
 #include "sppm_gather_tiles.hpp"
 #include "sppm_deposit.hpp"
+#include "sppm_deposit_wg.hpp"
 
 // ================================ host side / C ABI =================================================
 
@@ -566,7 +567,7 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
         if (hipStreamSynchronize(c->stream) != hipSuccess) { sppm_destroy(c); return fail(SPPM_ERR_HIP, "sppm_create: stream sync failed"); }
         c->sort_tmp_bytes = 0; c->d_sort_tmp = nullptr; c->order_valid = 0;
         TRY(dev_alloc(c, &c->d_est, (size_t)c->n_owned + 1)); TRY(dev_alloc(c, &c->d_items, (size_t)c->n_owned * 64 + 64, false)); TRY(dev_alloc(c, &c->d_items_raw, (size_t)c->n_owned * 64 + 64, false));
-        TRY(dev_alloc(c, &c->d_cell_tot, (size_t)c->table_cap / 4 + 1)); TRY(dev_alloc(c, &c->d_item_q, 2 + ITEM_CLASSES)); TRY(dev_alloc(c, &c->d_n_pieces, (size_t)c->n_owned + 1)); TRY(dev_alloc(c, &c->d_est_sum, 1)); TRY(dev_alloc(c, &c->d_ext_bin, (size_t)c->n_owned + 1)); c->est_valid = 0;
+        TRY(dev_alloc(c, &c->d_cell_tot, (size_t)c->table_cap / 4 + 1)); TRY(dev_alloc(c, &c->d_item_q, 2 + 2 * ITEM_CLASSES)); TRY(dev_alloc(c, &c->d_n_pieces, (size_t)c->n_owned + 1)); TRY(dev_alloc(c, &c->d_est_sum, 1)); TRY(dev_alloc(c, &c->d_ext_bin, (size_t)c->n_owned + 1)); c->est_valid = 0;
         c->split_factor = 4.0; c->est_per_photon = 0.0; c->est_range = 0;
         { const char* e = getenv("SPPM_SPLIT_FACTOR"); if (e && *e) c->split_factor = atof(e); }
         if (c->n_own_pix > 0) {
@@ -1518,8 +1519,7 @@ static int deposit_tiles(sppm_ctx* c)
     if (!c->order_valid) return fail(SPPM_ERR_STATE, "sppm_gather: no eye pass has run on this context yet");
     int rc = stats_read(c);
     if (rc) return rc;
-    rc = stats_launch(c);  // for the batch after this one
-    if (rc) return rc;
+    // (the statistics for the batch after this one are made by the plan and its two item kernels below: no launches of their own)
     if (!BS.binned) { rc = bin_into(c, c->cur, grid_for(c, c->rec_first, range), st, c->tile_stride > 1); if (rc) return rc; }
     const TileGrid g = BS.g;
     TileParams tp;
@@ -1531,15 +1531,22 @@ static int deposit_tiles(sppm_ctx* c)
     tp.cluster_d = c->gs.cluster_d;
     c->gather_j++;
     const int n_dep_tiles = (c->n_own_pix + DEP_TILE - 1) / DEP_TILE;  // DEP_H hitpoints per lane
-    hipLaunchKernelGGL(k_deposit_plan, dim3(nblk(n_dep_tiles, 4)), dim3(256), 0, st, c->hp, BS.cell_start, tp, n_dep_tiles, (uint32_t)c->dep_chunk, c->d_items_raw, c->d_n_pieces, c->d_est, c->d_item_q);
-    hipLaunchKernelGGL(k_items_hist, dim3(nblk(n_dep_tiles, 256)), dim3(256), 0, st, c->d_items_raw, c->d_n_pieces, n_dep_tiles, c->d_item_q);
-    hipLaunchKernelGGL(k_items_bases, dim3(1), dim3(64), 0, st, c->d_item_q, c->d_rec_count);
-    hipLaunchKernelGGL(k_items_scatter, dim3(nblk(n_dep_tiles, 256)), dim3(256), 0, st, c->d_items_raw, c->d_n_pieces, n_dep_tiles, c->d_item_q, c->d_items);
+    hipLaunchKernelGGL(k_deposit_plan, dim3(nblk(n_dep_tiles, 4)), dim3(256), 0, st, c->hp, BS.cell_start, tp, n_dep_tiles, (uint32_t)c->dep_chunk, c->d_items_raw, c->d_n_pieces, c->d_est, c->d_item_q,
+                       c->d_ext_bin, c->d_stats);
+    hipLaunchKernelGGL(k_items_count, dim3(nblk(n_dep_tiles, 256)), dim3(256), 0, st, c->d_items_raw, c->d_n_pieces, n_dep_tiles, c->d_item_q, c->d_ext_bin, c->d_stats);
+    hipLaunchKernelGGL(k_items_place, dim3(nblk(n_dep_tiles, 256)), dim3(256), 0, st, c->d_items_raw, c->d_n_pieces, n_dep_tiles, c->d_item_q, c->d_items, c->d_rec_count,
+                       c->d_stats, c->d_hp_bb, c->d_counters, c->d_stat_map + c->stat_w);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(c->ev_stat[c->stat_w], st));
+    c->stat_w ^= 1; c->stat_n++;
     c->est_valid = 0;  // (the estimates of the ordered gather's plan are not made here)
     const int blocks = std::max(1, std::min(nblk(n_dep_tiles, 4) * 4, (int)env_i64("SPPM_DEP_BLOCKS", 256 * 3)));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->timing) { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventRecord(e0, st)); }
     const bool stamps = getenv("SPPM_STAMPS") != nullptr;
+    // SPPM_DEP_WG=1: the workgroup form with the distance test on the matrix pipe (sppm_deposit_wg.hpp) -- the same deposits
+    // bit for bit, measured SLOWER than the default; kept as the record of that experiment
+    const bool dep_wg = env_i64("SPPM_DEP_WG", 0) != 0 && DEP_H == 1;
     if (stamps) {
         HIPCHK(hipMemsetAsync(c->d_counters + 15, 0, 9 * sizeof(unsigned long long), st));
         hipLaunchKernelGGL((k_deposit_tiles<false, true>), dim3(blocks), dim3(256), 0, st, c->hp, BS.rec_s, BS.cell_start, tp, c->d_items, c->d_item_q, c->d_counters, c->d_err);
@@ -1550,6 +1557,9 @@ static int deposit_tiles(sppm_ctx* c)
         fprintf(stderr, "[sppm] deposit: items %llu, shares of wave cycles: setup %.1f%% count %.1f%% issue %.1f%% append %.1f%% (of it waiting for the group's loads %.1f%%) process %.1f%% flush %.1f%%; grid %dx%dx%d\n", t[7],
                 100.0 * t[16] / tot, 100.0 * t[17] / tot, 100.0 * t[18] / tot, 100.0 * t[19] / tot, 100.0 * t[23] / tot, 100.0 * t[20] / tot, 100.0 * t[21] / tot, g.nx, g.ny, g.nz);
         fprintf(stderr, "[sppm]   staged records by class: distance test only %llu, full test %llu (records rejected for the whole cluster are not staged)\n", t[22], t[15]);
+    } else if (dep_wg) {
+        if (c->tap_cap > 0) hipLaunchKernelGGL(k_deposit_wg<true>, dim3(blocks), dim3(256), 0, st, c->hp, BS.rec_s, BS.cell_start, tp, c->d_items, c->d_item_q, c->d_counters, c->d_err);
+        else hipLaunchKernelGGL(k_deposit_wg<false>, dim3(blocks), dim3(256), 0, st, c->hp, BS.rec_s, BS.cell_start, tp, c->d_items, c->d_item_q, c->d_counters, c->d_err);
     } else if (c->tap_cap > 0)
         hipLaunchKernelGGL(k_deposit_tiles<true>, dim3(blocks), dim3(256), 0, st, c->hp, BS.rec_s, BS.cell_start, tp, c->d_items, c->d_item_q, c->d_counters, c->d_err);
     else

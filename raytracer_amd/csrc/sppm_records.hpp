@@ -103,8 +103,11 @@ __device__ __forceinline__ long long fx_fix(double v, double scale, bool& clampe
 // rows != 0 (the tile gathers read dst): dst is laid out record by record, REC_ROW doubles each: position, geometric
 // normal, flux, key.  The gathers read every record of a cell region many times, a few consecutive records at a time: as
 // rows those are one or two cache lines, as nine planes nine -- and this kernel writes 80 contiguous bytes per record.
-// fx_scale > 0 (the per-pass rule's deposit kernel): the flux is written as the 64-bit fixed point of the deposits
-// (fx_fix, bits in the double's place) -- once per record here instead of once per cluster that stages it.
+// fx_scale > 0 (the per-pass rule's deposit kernel): the flux is written as the fixed point of the deposits (fx_fix: an
+// integer of at most 42 bits, stored as the double of that value) -- once per record here instead of once per cluster
+// that stages it.  Sums of fewer than 2^11 such values are exact in double arithmetic, in any order: the deposit kernel
+// adds them with v_add_f64 (and the matrix pipe's result feeds only comparisons) and moves them to 64-bit integers
+// before a sum can reach 2^53.
 #define REC_ROW 10
 __global__ void k_grid_scatter(RecArrays src, RecArrays dst, const unsigned long long* __restrict__ rec_count,
                                const uint32_t* __restrict__ rec_bucket, uint32_t* __restrict__ cursor, int rows, double fx_scale, int32_t* __restrict__ err)
@@ -120,7 +123,7 @@ __global__ void k_grid_scatter(RecArrays src, RecArrays dst, const unsigned long
             for (int c = 0; c < 9; c++) v[c] = src.f[c * src.cap + i];
             if (fx_scale > 0.0) {
 #pragma unroll
-                for (int c = 6; c < 9; c++) v[c] = __longlong_as_double(fx_fix(v[c], fx_scale, clamped));
+                for (int c = 6; c < 9; c++) v[c] = (double)fx_fix(v[c], fx_scale, clamped);  // an integer below 2^41 + 1: exact as a double
             }
             v[9] = __longlong_as_double((long long)src.key[i]);
             double2* row = (double2*)(dst.f + (size_t)REC_ROW * p);

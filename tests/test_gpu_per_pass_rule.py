@@ -69,8 +69,6 @@ def test_deposits_do_not_depend_on_how_the_work_is_cut(monkeypatch):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         ctx = sppm.SppmContext(sppm.make_config(W, H, photons_per_pass=M, update_rule=1))
-        for k in env:
-            monkeypatch.delenv(k)
         for i in range(2):
             ctx.eye_pass(i)
             if halves:
@@ -80,13 +78,17 @@ def test_deposits_do_not_depend_on_how_the_work_is_cut(monkeypatch):
                 ctx.photon_pass(i, M)
             ctx.end_pass()
         ctx.check()
+        for k in env:  # (most switches are read when the context is made, SPPM_DEP_WG at every deposit)
+            monkeypatch.delenv(k)
         s = ctx.hitpoints()
         img = ctx.resolve(1, M).cpu().numpy()
         ctx.close()
         return s, img
     ref_s, ref_img = run({})
     for env, halves in (({"SPPM_DEP_CHUNK": "64"}, False), ({"SPPM_GATHER_TILES": "0"}, False), ({"SPPM_BATCH_PHOTONS": "4096"}, False),
-                        ({}, True), ({"SPPM_DEP_CELL_FACTOR": "0.6"}, False), ({"SPPM_PREFETCH": "0"}, False)):
+                        ({}, True), ({"SPPM_DEP_CELL_FACTOR": "0.6"}, False), ({"SPPM_PREFETCH": "0"}, False),
+                        # the workgroup form with the distance test on the matrix pipe (v_mfma_f64_16x16x4_f64), an experiment kept in the tree
+                        ({"SPPM_DEP_WG": "1"}, False), ({"SPPM_DEP_WG": "1", "SPPM_DEP_CHUNK": "64"}, False), ({"SPPM_DEP_WG": "1", "SPPM_BATCH_PHOTONS": "4096"}, False)):
         s, img = run(env, halves)
         for k in ("n", "r2", "flux"):
             _same(s[k], ref_s[k], f"{env} {k}")

@@ -16,8 +16,9 @@ for line in sys.stdin:
     k, v = m.group(1), m.group(2).strip()
     if k == "name" and not v.startswith("_Z") and not v.startswith("k_") : continue
     if k in ("vgpr_count", "sgpr_count", "private_segment_fixed_size", "group_segment_fixed_size", "agpr_count", "vgpr_spill_count"): row[k] = v
-    if k == "symbol":
-        print(v.replace(".kd", "")[:70].ljust(70), " ".join(f"{a}={row.get(b)}" for a, b in (("vgpr", "vgpr_count"), ("agpr", "agpr_count"), ("sgpr", "sgpr_count"), ("scratch", "private_segment_fixed_size"), ("lds", "group_segment_fixed_size"), ("spill", "vgpr_spill_count"))))
+    if k == "symbol": row["symbol"] = v
+    if k == "wavefront_size":  # the last key of an entry (keys are in alphabetical order)
+        print(row.get("symbol", "?").replace(".kd", "")[:70].ljust(70), " ".join(f"{a}={row.get(b)}" for a, b in (("vgpr", "vgpr_count"), ("agpr", "agpr_count"), ("sgpr", "sgpr_count"), ("scratch", "private_segment_fixed_size"), ("lds", "group_segment_fixed_size"), ("spill", "vgpr_spill_count"))))
         row = {}
 '
 rm -rf $T
