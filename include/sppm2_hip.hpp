@@ -8,7 +8,8 @@
 //
 // Differences from the reference, all deliberate:
 //   * the scene is run-time data (`edupt::spheres` is a mutable std::vector initialised to the
-//     reference's table, src/scene.h:12-24) instead of a const global compiled into every TU;
+//     reference's table, src/scene.h:12-24; `edupt::scene()` returns the same object) instead of a const global
+//     compiled into every TU;
 //   * random numbers come from per-(pass,pixel) and per-photon XorShift streams (src/random.h)
 //     seeded from `seed_eye` / `seed_photon`, not from std::random_device, so a render is reproducible;
 //   * photon_count starts at 0 (the reference leaves it uninitialised, src/sppm2.h:108-116);
@@ -18,6 +19,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <cmath>
+#include <cstdint>
 #include <string>
 #include <vector>
 
@@ -36,8 +38,39 @@ namespace edupt
         double length_squared() const { return x * x + y * y + z * z; }
         double length() const { return std::sqrt(length_squared()); }
     };
+    inline Vec operator*(double f, const Vec& v) { return v * f; }
     inline Vec normalize(const Vec& v) { return v * (1.0 / v.length()); }
+    inline const Vec multiply(const Vec& v1, const Vec& v2) { return Vec(v1.x * v2.x, v1.y * v2.y, v1.z * v2.z); }
+    inline double dot(const Vec& v1, const Vec& v2) { return v1.x * v2.x + v1.y * v2.y + v1.z * v2.z; }
+    inline const Vec cross(const Vec& v1, const Vec& v2)
+    {
+        return Vec((v1.y * v2.z) - (v1.z * v2.y), (v1.z * v2.x) - (v1.x * v2.z), (v1.x * v2.y) - (v1.y * v2.x));
+    }
     typedef Vec Color;  // src/material.h:8
+
+    // src/constant.h:6-8
+    const double kPI = 3.14159265358979323846;
+    const double kINF = 1e128;
+    const double kEPS = 1e-6;
+
+    // src/ray.h:8-12
+    struct Ray {
+        Vec org, dir;
+        Ray(const Vec& org_, const Vec& dir_) : org(org_), dir(dir_) {}
+    };
+
+    // src/intersection.h:9-24
+    struct Hitpoint {
+        double distance;
+        Vec normal;
+        Vec position;
+        Hitpoint() : distance(kINF), normal(), position() {}
+    };
+    struct Intersection {
+        Hitpoint hitpoint;
+        int object_id;
+        Intersection() : object_id(-1) {}
+    };
 
     // src/material.h:10-17
     enum ReflectionType { REFLECTION_TYPE_DIFFUSE, REFLECTION_TYPE_SPECULAR, REFLECTION_TYPE_REFRACTION };
@@ -70,6 +103,9 @@ namespace edupt
         return s;
     }
 
+    // the reference's name for the table (src/scene.h:12): `edupt::spheres[i]`, `edupt::spheres.size()`
+    inline std::vector<Sphere>& spheres = scene();
+
     // the scene as the C ABI takes it
     inline std::vector<sppm_sphere> c_scene()
     {
@@ -84,6 +120,90 @@ namespace edupt
             sp.push_back(o);
         }
         return sp;
+    }
+
+    // src/cameras.h:11-65: the same members, the same expressions in the same order (host arithmetic; the kernels' camera
+    // is set up by sppm_create from the same numbers and gives the same rays bit for bit: tests/test_gpu_parity.py)
+    class PinholeCamera
+    {
+    public:
+        const double image_width;
+        const double image_height;
+        const double screen_width;
+        const double screen_height;
+        const double screen_dist = 40.0;
+        const Vec camera_position;
+        const Vec camera_dir;
+        const Vec camera_up;
+        double supersamples;
+        const Vec screen_x;
+        const Vec screen_y;
+        const Vec screen_center;
+
+        PinholeCamera(const double width, const double height, const double screen_height_, const double screen_dist_, const Vec& camera_position_,
+                      const Vec& camera_dir_, const Vec& camera_up_, const double supersamples_)
+            : image_width(width), image_height(height), screen_width(screen_height_ * width / height), screen_height(screen_height_),
+              screen_dist(screen_dist_), camera_position(camera_position_), camera_dir(camera_dir_), camera_up(camera_up_),
+              supersamples(supersamples_), screen_x(normalize(cross(camera_dir, camera_up)) * screen_width),
+              screen_y(normalize(cross(screen_x, camera_dir)) * screen_height), screen_center(camera_position + camera_dir * screen_dist)
+        {
+        }
+
+        Ray get_ray(const double x, const double y, const int supersample_x = 0, const int supersample_y = 0)
+        {
+            const double rate = (1.0 / supersamples);
+            const double r1 = supersample_x * rate + rate / 2.0;
+            const double r2 = supersample_y * rate + rate / 2.0;
+            const Vec screen_position = screen_center + screen_x * ((r1 + x) / image_width - 0.5) + screen_y * ((r2 + y) / image_height - 0.5);
+            const Vec dir = normalize(screen_position - camera_position);
+            return Ray(camera_position, dir);
+        }
+    };
+
+    // intersect_scene (src/scene.h:53-76) for a batch of rays, on the GPU: the closest hit over `spheres`, lowest index on
+    // ties, through sppm_intersect_static (no context; at most 512 spheres -- larger scenes go through sppm_create /
+    // sppm_intersect, which walk a grid).  Returns 0 or a negative sppm_status.
+    inline int intersect_scene(const std::vector<Ray>& rays, std::vector<Intersection>* out)
+    {
+        const size_t n = rays.size();
+        out->assign(n, Intersection());
+        if (n == 0) return 0;
+        std::vector<double> h_rays(6 * n), h_hit(7 * n);
+        std::vector<int32_t> h_id(n);
+        for (size_t i = 0; i < n; i++) {
+            double* r = &h_rays[6 * i];
+            r[0] = rays[i].org.x; r[1] = rays[i].org.y; r[2] = rays[i].org.z; r[3] = rays[i].dir.x; r[4] = rays[i].dir.y; r[5] = rays[i].dir.z;
+        }
+        double *d_rays = nullptr, *d_hit = nullptr;
+        int32_t* d_id = nullptr;
+        int rc = SPPM_ERR_HIP;
+        if (hipMalloc((void**)&d_rays, 6 * n * sizeof(double)) == hipSuccess && hipMalloc((void**)&d_hit, 7 * n * sizeof(double)) == hipSuccess &&
+            hipMalloc((void**)&d_id, n * sizeof(int32_t)) == hipSuccess &&
+            hipMemcpy(d_rays, h_rays.data(), 6 * n * sizeof(double), hipMemcpyHostToDevice) == hipSuccess) {
+            const std::vector<sppm_sphere> sp = c_scene();
+            rc = sppm_intersect_static(sp.data(), (int32_t)sp.size(), d_rays, (int64_t)n, d_id, d_hit, nullptr, nullptr);
+            if (!rc && (hipMemcpy(h_id.data(), d_id, n * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess ||
+                        hipMemcpy(h_hit.data(), d_hit, 7 * n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)) rc = SPPM_ERR_HIP;
+        }
+        (void)hipFree(d_rays); (void)hipFree(d_hit); (void)hipFree(d_id);
+        if (rc) return rc;
+        for (size_t i = 0; i < n; i++) {
+            Intersection& is = (*out)[i];
+            is.object_id = h_id[i];
+            const double* f = &h_hit[7 * i];
+            is.hitpoint.distance = f[0];
+            if (is.object_id >= 0) { is.hitpoint.position = Vec(f[1], f[2], f[3]); is.hitpoint.normal = Vec(f[4], f[5], f[6]); }
+        }
+        return 0;
+    }
+    // the reference's signature (src/scene.h:53): one ray.  A batch of one on the GPU -- for drop-in use; callers with
+    // many rays use the batch form above.
+    inline bool intersect_scene(const Ray& ray, Intersection* intersection)
+    {
+        std::vector<Intersection> out;
+        if (intersect_scene(std::vector<Ray>(1, ray), &out) != 0) { *intersection = Intersection(); return false; }
+        *intersection = out[0];
+        return intersection->object_id != -1;
     }
 
     // src/ppm.h:22 and src/hdr.h:48 (the reference puts save_hdr_file in photonmap::utility)

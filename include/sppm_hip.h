@@ -159,7 +159,9 @@ int sppm_intersect(sppm_ctx* ctx, const double* d_rays, int64_t n, int32_t* d_id
  * (a hipStream_t, NULL = the default stream): no hipMalloc / hipFree / host-sourced copy.  d_rays[n][6],
  * d_id[n], d_hit[n][7] as for sppm_intersect; d_n_hit (device, may be NULL) receives the number of rays that hit.
  * More than 512 spheres: SPPM_ERR_INVALID (such scenes need sppm_create, which builds a grid).  Every call on a
- * GPU shares that GPU's array: calls that overlap on one GPU (different streams or threads) race -- serialise them. */
+ * GPU shares that GPU's array: calls that overlap on one GPU (different streams or threads) race -- serialise them.
+ * The array is the CURRENT device's: `stream` must belong to it (checked).  The first call on a device (or sppm_create
+ * on it) looks the array's address up; make that call outside stream capture, later calls can be captured. */
 int sppm_intersect_static(const sppm_sphere* h_spheres, int32_t n_spheres, const double* d_rays, int64_t n, int32_t* d_id,
                           double* d_hit, uint64_t* d_n_hit, void* stream);
 

@@ -265,12 +265,15 @@ __global__ void __launch_bounds__(256) k_items_place(const unsigned long long* _
 #define DEP_ATTR __attribute__((amdgpu_waves_per_eu(DEP_WAVES, DEP_WAVES)))
 #define DEP_FLUSH_ROWS 2048  // staged rows after which the double sums move to the 64-bit integers (2048 x 2^41 = 2^52)
 #define DEP_ROWS 64  // staged records per wavefront: one group of candidates at a time, processed while the next group's loads are in flight
-template <bool TAP, bool STAMPS = false>
+// VETO: the reference's K cap is enforced (sppm_cap.hpp): a pair the capped kd search dropped is in tp.veto and is not
+// deposited (src/stochastic_ppm.h:425-427 hand gahter_max_photon_num to the same SearchNearest as src/sppm2.h).
+template <bool TAP, bool STAMPS = false, bool VETO = false>
 __global__ void __launch_bounds__(256) DEP_ATTR k_deposit_tiles(HpArrays hp, RecArrays rec, const uint32_t* __restrict__ cell_start, TileParams tp,
                                                        const uint32_t* __restrict__ items, unsigned int* __restrict__ q,
                                                        unsigned long long* __restrict__ counters, int32_t* __restrict__ err)
 {
-    constexpr int ROW = TAP ? 11 : 10;
+    constexpr bool KEYS = TAP || VETO;  // the staged rows carry the record's key
+    constexpr int ROW = KEYS ? 11 : 10;
     // a staged record of the full test: position, geometric normal, fixed-point flux (integer-valued doubles); of the distance-only
     // test: position about the cluster's centre, its square, flux, position; [ROW - 1: key bits]
     __shared__ double s_row[4][DEP_ROWS][ROW];
@@ -458,7 +461,7 @@ __global__ void __launch_bounds__(256) DEP_ATTR k_deposit_tiles(HpArrays hp, Rec
                 const double2* rp = (const double2*)(rec.f + (size_t)REC_ROW * p_r);  /* one row: sppm_records.hpp */   \
                 const double2 ra = rp[0], rb = rp[1], rc = rp[2], rd = rp[3], re = rp[4];                              \
                 p0 = ra.x; p1 = ra.y; p2 = rb.x; p3 = rb.y; p4 = rc.x; p5 = rc.y; p6 = rd.x; p7 = rd.y; p8 = re.x;     \
-                if (TAP) p_key = (unsigned long long)__double_as_longlong(re.y);                                       \
+                if (KEYS) p_key = (unsigned long long)__double_as_longlong(re.y);                                      \
             }                                                                                                          \
             cbase += 64;                                                                                               \
         }                                                                                                              \
@@ -501,7 +504,7 @@ __global__ void __launch_bounds__(256) DEP_ATTR k_deposit_tiles(HpArrays hp, Rec
                     row[0] = p0; row[1] = p1; row[2] = p2; row[3] = p3; row[4] = p4; row[5] = p5;
                     row[6] = f6; row[7] = f7; row[8] = f8;
                 }
-                if (TAP) row[ROW - 1] = __longlong_as_double((long long)p_key);
+                if (KEYS) row[ROW - 1] = __longlong_as_double((long long)p_key);
             }
             n_easy = __popcll(m_e); n_full = __popcll(m_f);
             sel_n = n_easy + n_full;
@@ -523,7 +526,7 @@ __global__ void __launch_bounds__(256) DEP_ATTR k_deposit_tiles(HpArrays hp, Rec
         // Two records per trip (independent chains of LDS read -> three fused multiply-adds -> compares); a pair too
         // close to call (see E above) is left out here and only noted in `und` -- the loop carries no branch for it.
 #define DEP_TAKE(rowp)                                                                                                 \
-        {                                                                                                              \
+        if (!VETO || !veto_has(tp.veto, (unsigned long long)__double_as_longlong((rowp)[ROW - 1]), t.p[0])) {          \
             ax[0] += (rowp)[4]; ay[0] += (rowp)[5]; az[0] += (rowp)[6]; am[0]++;                                      \
             if (TAP) {                                                                                                 \
                 const unsigned long long ts = atomicAdd(tp.tap_n, 1ull);                                               \
@@ -606,7 +609,7 @@ __global__ void __launch_bounds__(256) DEP_ATTR k_deposit_tiles(HpArrays hp, Rec
                 const double fx = row[6], fy = row[7], fz = row[8];
 #pragma unroll
                 for (int h = 0; h < DEP_H; h++) {
-                    if (ok[h]) {
+                    if (ok[h] && (!VETO || !veto_has(tp.veto, (unsigned long long)__double_as_longlong(row[ROW - 1]), t.p[h]))) {
                         ax[h] += fx; ay[h] += fy; az[h] += fz; am[h]++;
                         if (TAP) {
                             const unsigned long long ts = atomicAdd(tp.tap_n, 1ull);

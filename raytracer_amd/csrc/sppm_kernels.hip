@@ -163,6 +163,9 @@ struct sppm_ctx {
     // (host), the same on the device, one heap per search lane, the table of dropped pairs the gathers consult
     std::vector<int32_t> kd_order; std::vector<uint8_t> kd_listed; int kd_pass, kd_fallback;
     int32_t* d_kd; int64_t kd_cap;
+    // the K cap's filter (sppm_cap.hpp): hitpoint counts on a coarse grid, the photon hits whose bound exceeds K
+    uint32_t* d_cap_cnt; int64_t cap_cnt_cap; CapGrid cap_grid; uint32_t* d_cap_surv; int64_t cap_surv_cap; unsigned long long* d_cap_nsurv;
+    uint64_t cap_filtered;  // photon hits that passed the filter so far
     double* d_heap_d2; int32_t* d_heap_pix; int64_t heap_cap_d, heap_cap_x;
     unsigned long long* d_veto_tab; int64_t veto_entries; unsigned long long *d_veto_n, *d_cap_stat;
     Veto veto_dev;  // what the gathers get: n == nullptr while the cap cannot act
@@ -355,6 +358,7 @@ static int build_scene_grid(sppm_ctx* c, const sppm_sphere* sp, int n)
 static void set_cur(sppm_ctx* c, int b);
 static int ppm_prepare(sppm_ctx* c);
 
+static int static_scratch(unsigned char** out);  // (sppm_intersect_static, at the end of this file)
 extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres, int32_t n_spheres, void* stream, sppm_ctx** out)
 {
     if (!cfg || !h_spheres || !out || n_spheres < 1) return fail(SPPM_ERR_INVALID, "sppm_create: null argument or empty scene");
@@ -368,6 +372,11 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
     if (cfg->update_rule != 0 && cfg->update_rule != 1) return fail(SPPM_ERR_INVALID, "sppm_create: update_rule must be 0 or 1");
     if (cfg->ownership != 0 && cfg->ownership != 1) return fail(SPPM_ERR_INVALID, "sppm_create: ownership must be 0 (screen tiles) or 1 (ranges of the hitpoints' Morton order)");
     if (cfg->sampler != 0 && cfg->sampler != 1) return fail(SPPM_ERR_INVALID, "sppm_create: sampler must be 0 (XorShift streams) or 1 (reference mt19937 stream)");
+    // the per-pass rule shards PHOTONS over ranks (every rank keeps all hitpoints and the deposits are all-reduced); with a
+    // share of the hitpoints per rank the end-of-pass kernels would leave the imported sums of the hitpoints a rank does
+    // not own in place, to be exported and counted again in the next pass
+    if (cfg->update_rule == 1 && cfg->tile_stride > 1)
+        return fail(SPPM_ERR_INVALID, "sppm_create: update_rule 1 keeps all hitpoints on every rank (tile_stride 0 or 1); hitpoint ownership (tile_stride > 1) is for update_rule 0");
     if (cfg->tracer_variant != 0 && cfg->tracer_variant != 1) return fail(SPPM_ERR_INVALID, "sppm_create: tracer_variant must be 0 (src/sppm2.h) or 1 (src/stochastic_ppm.h as shipped)");
     if (cfg->tracer_variant == 1 && (cfg->sampler != 1 || cfg->algorithm != 0)) return fail(SPPM_ERR_INVALID, "sppm_create: tracer_variant 1 reproduces runs of the compiled src/stochastic_ppm.h and needs sampler 1, algorithm 0");
     if (cfg->algorithm != 0 && cfg->algorithm != 1) return fail(SPPM_ERR_INVALID, "sppm_create: algorithm must be 0 (sppm2.h) or 1 (progressive_photonmapping.h)");
@@ -583,6 +592,10 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
 #undef TRY
     set_cur(c, 0);
     if (hipStreamSynchronize(c->stream) != hipSuccess) { sppm_destroy(c); return fail(SPPM_ERR_HIP, "sppm_create: stream sync failed"); }
+    // (the address of sppm_intersect_static's array on this device is looked up here, outside any stream capture, so that
+    // a captured first call of that entry point has no symbol to resolve; a caller without a context makes one plain
+    // call before capturing)
+    { unsigned char* unused = nullptr; (void)static_scratch(&unused); }
     *out = c;
     return SPPM_OK;
 }
@@ -608,6 +621,9 @@ extern "C" int sppm_destroy(sppm_ctx* c)
     if (c->ev_rows) hipEventDestroy(c->ev_rows);
     for (int b = 0; b < 2; b++) if (c->ev_stat[b]) hipEventDestroy(c->ev_stat[b]);
     if (c->d_kd) hipFree(c->d_kd);
+    if (c->d_cap_cnt) hipFree(c->d_cap_cnt);
+    if (c->d_cap_surv) hipFree(c->d_cap_surv);
+    if (c->d_cap_nsurv) hipFree(c->d_cap_nsurv);
     if (c->d_heap_d2) hipFree(c->d_heap_d2);
     if (c->d_heap_pix) hipFree(c->d_heap_pix);
     if (c->d_veto_tab) hipFree(c->d_veto_tab);
@@ -1529,6 +1545,7 @@ static int deposit_tiles(sppm_ctx* c)
     tp.tap_key = c->d_tap_key; tp.tap_pix = c->d_tap_pix; tp.tap_n = c->d_tap_n; tp.tap_cap = c->tap_cap;
     tp.g = g;
     tp.cluster_d = c->gs.cluster_d;
+    tp.veto = c->veto_dev;
     c->gather_j++;
     const int n_dep_tiles = (c->n_own_pix + DEP_TILE - 1) / DEP_TILE;  // DEP_H hitpoints per lane
     hipLaunchKernelGGL(k_deposit_plan, dim3(nblk(n_dep_tiles, 4)), dim3(256), 0, st, c->hp, BS.cell_start, tp, n_dep_tiles, (uint32_t)c->dep_chunk, c->d_items_raw, c->d_n_pieces, c->d_est, c->d_item_q,
@@ -1557,6 +1574,9 @@ static int deposit_tiles(sppm_ctx* c)
         fprintf(stderr, "[sppm] deposit: items %llu, shares of wave cycles: setup %.1f%% count %.1f%% issue %.1f%% append %.1f%% (of it waiting for the group's loads %.1f%%) process %.1f%% flush %.1f%%; grid %dx%dx%d\n", t[7],
                 100.0 * t[16] / tot, 100.0 * t[17] / tot, 100.0 * t[18] / tot, 100.0 * t[19] / tot, 100.0 * t[23] / tot, 100.0 * t[20] / tot, 100.0 * t[21] / tot, g.nx, g.ny, g.nz);
         fprintf(stderr, "[sppm]   staged records by class: distance test only %llu, full test %llu (records rejected for the whole cluster are not staged)\n", t[22], t[15]);
+    } else if (c->veto_dev.n != nullptr) {  // the K cap acts on this batch: the pairs it dropped are withheld
+        if (c->tap_cap > 0) hipLaunchKernelGGL((k_deposit_tiles<true, false, true>), dim3(blocks), dim3(256), 0, st, c->hp, BS.rec_s, BS.cell_start, tp, c->d_items, c->d_item_q, c->d_counters, c->d_err);
+        else hipLaunchKernelGGL((k_deposit_tiles<false, false, true>), dim3(blocks), dim3(256), 0, st, c->hp, BS.rec_s, BS.cell_start, tp, c->d_items, c->d_item_q, c->d_counters, c->d_err);
     } else if (dep_wg) {
         if (c->tap_cap > 0) hipLaunchKernelGGL(k_deposit_wg<true>, dim3(blocks), dim3(256), 0, st, c->hp, BS.rec_s, BS.cell_start, tp, c->d_items, c->d_item_q, c->d_counters, c->d_err);
         else hipLaunchKernelGGL(k_deposit_wg<false>, dim3(blocks), dim3(256), 0, st, c->hp, BS.rec_s, BS.cell_start, tp, c->d_items, c->d_item_q, c->d_counters, c->d_err);
@@ -1622,14 +1642,39 @@ static int cap_build_tree(sppm_ctx* c)
     cap_sort_range(c->kd_order.data(), pos.data(), P, 0, n, 0, 4);
     if (grow(c, &c->d_kd, &c->kd_cap, std::max<int64_t>(n, 1))) return SPPM_ERR_HIP;
     HIPCHK(hipMemcpy(c->d_kd, c->kd_order.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    {   // the filter's grid: the tree's hitpoints counted in cells of half the search radius (at most 2^22 cells)
+        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+        for (int i = 0; i < n; i++)
+            for (int a = 0; a < 3; a++) { const double v = pos[(size_t)a * P + c->kd_order[(size_t)i]]; lo[a] = std::min(lo[a], v); hi[a] = std::max(hi[a], v); }
+        if (n == 0) for (int a = 0; a < 3; a++) lo[a] = hi[a] = 0.0;
+        double cell = 0.5 * std::sqrt(c->cfg.gather_radius2);
+        if (!(cell > 0.0)) cell = 1.0;
+        int64_t dims[3];
+        for (;;) {
+            int64_t cells = 1;
+            for (int a = 0; a < 3; a++) { dims[a] = std::max<int64_t>(1, (int64_t)std::floor((hi[a] - lo[a]) / cell) + 1); cells *= dims[a]; if (cells > (1ll << 40)) break; }
+            if (cells <= (1ll << 22)) break;
+            cell *= 1.26;
+        }
+        CapGrid& g = c->cap_grid;
+        g.ox = lo[0]; g.oy = lo[1]; g.oz = lo[2]; g.inv_c = 1.0 / cell; g.nx = (int)dims[0]; g.ny = (int)dims[1]; g.nz = (int)dims[2];
+        std::vector<uint32_t> cnt((size_t)(dims[0] * dims[1] * dims[2]), 0u);
+        auto coord = [](double v, double o, double inv, int nn) { int q = (int)std::floor((v - o) * inv); return q < 0 ? 0 : (q >= nn ? nn - 1 : q); };  // as grid_coord on the device
+        for (int i = 0; i < n; i++) {
+            const size_t h = (size_t)c->kd_order[(size_t)i];
+            const int ix = coord(pos[h], g.ox, g.inv_c, g.nx), iy = coord(pos[(size_t)P + h], g.oy, g.inv_c, g.ny), iz = coord(pos[2 * (size_t)P + h], g.oz, g.inv_c, g.nz);
+            cnt[((size_t)iz * g.ny + iy) * g.nx + ix]++;
+        }
+        if (grow(c, &c->d_cap_cnt, &c->cap_cnt_cap, (int64_t)cnt.size())) return SPPM_ERR_HIP;
+        HIPCHK(hipMemcpy(c->d_cap_cnt, cnt.data(), cnt.size() * 4, hipMemcpyHostToDevice));
+        g.cnt = c->d_cap_cnt;
+    }
     c->kd_pass = c->last_eye_pass;
     return 0;
 }
 // the capped search of every record in the current buffer; leaves the dropped pairs in the Veto table
 static int cap_search(sppm_ctx* c)
 {
-    if (c->cfg.update_rule == 1)
-        return fail(SPPM_ERR_INVALID, "gather_max is below the number of hitpoints, so the reference's K cap could act; the exact capped search is built for update_rule 0 (set check_gather_max = 2 to run the per-pass rule uncapped)");
     int rc = cap_build_tree(c);
     if (rc) return rc;
     const int n = (int)c->kd_order.size();
@@ -1637,10 +1682,22 @@ static int cap_search(sppm_ctx* c)
     hipStream_t st = c->stream;
     const int64_t K = c->cfg.gather_max;
     if (K < 0) return fail(SPPM_ERR_INVALID, "gather_max is negative");
+    // the photon hits the cap can act on at all (k_cap_filter): usually a few percent, often none
+    if (grow(c, &c->d_cap_surv, &c->cap_surv_cap, c->rec_u.cap)) return SPPM_ERR_HIP;
+    if (!c->d_cap_nsurv) HIPCHK(hipMalloc((void**)&c->d_cap_nsurv, 8));
+    HIPCHK(hipMemsetAsync(c->d_cap_nsurv, 0, 8, st));
+    const double reach = std::sqrt(c->cfg.gather_radius2) * (1.0 + 1e-9) + 1e-9;
+    hipLaunchKernelGGL(k_cap_filter, dim3(1024), dim3(256), 0, st, c->rec_u, c->d_rec_count, c->cap_grid, reach, (long long)K, c->d_cap_surv, c->d_cap_nsurv);
+    HIPCHK(hipGetLastError());
+    unsigned long long n_surv = 0;
+    HIPCHK(hipMemcpyAsync(&n_surv, c->d_cap_nsurv, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    c->cap_filtered += n_surv;
+    if (n_surv == 0) return 0;  // no photon hit of this batch can see more than K hitpoints: the cap cannot act
     const int64_t stride = K + 1;
     const int64_t budget = env_i64("SPPM_CAP_HEAP_MB", 4096) << 20;
     int64_t lanes = std::min<int64_t>(65536, std::max<int64_t>(64, budget / (12 * stride)));
-    lanes = std::min<int64_t>(lanes, (c->rec_u.cap + 63) / 64 * 64);
+    lanes = std::min<int64_t>(lanes, ((int64_t)n_surv + 63) / 64 * 64);  // heaps for the photon hits that need one
     lanes = std::max<int64_t>(64, lanes / 64 * 64);
     if (grow(c, &c->d_heap_d2, &c->heap_cap_d, lanes * stride) || grow(c, &c->d_heap_pix, &c->heap_cap_x, lanes * stride)) return SPPM_ERR_HIP;
     if (!c->d_veto_n) { HIPCHK(hipMalloc((void**)&c->d_veto_n, 8)); HIPCHK(hipMalloc((void**)&c->d_cap_stat, 32)); }
@@ -1654,6 +1711,7 @@ static int cap_search(sppm_ctx* c)
         HIPCHK(hipMemsetAsync(c->d_cap_stat, 0, 32, st));
         CapParams cp;
         memset(&cp, 0, sizeof cp);
+        cp.surv = c->d_cap_surv; cp.n_surv = (long long)n_surv;
         cp.kd = c->d_kd; cp.n = n; cp.R0 = c->cfg.gather_radius2; cp.K = K;
         cp.heap_d2 = c->d_heap_d2; cp.heap_pix = c->d_heap_pix; cp.heap_stride = stride; cp.lanes = (int)lanes;
         cp.veto.tab = c->d_veto_tab; cp.veto.mask = (unsigned long long)c->veto_entries - 1ull; cp.veto.n = c->d_veto_n;
@@ -1668,7 +1726,7 @@ static int cap_search(sppm_ctx* c)
         if (got <= cp.veto_cap) {
             c->cap_capped += stat[0]; c->cap_nodes += stat[1]; c->cap_max_fill = std::max<uint64_t>(c->cap_max_fill, stat[2]); c->cap_vetoes += got;
             c->veto_dev = cp.veto;
-            if (getenv("SPPM_DEBUG")) fprintf(stderr, "[sppm] K cap: %llu queries capped, %llu nodes walked, %llu pairs dropped (table %lld entries, %lld lanes)\n", stat[0], stat[1], got, (long long)c->veto_entries, (long long)lanes);
+            if (getenv("SPPM_DEBUG")) fprintf(stderr, "[sppm] K cap: %llu photon hits past the filter, %llu queries capped, %llu nodes walked, %llu pairs dropped (table %lld entries, %lld lanes)\n", n_surv, stat[0], stat[1], got, (long long)c->veto_entries, (long long)lanes);
             return 0;
         }
         if (attempt >= 2) return fail(SPPM_ERR_OVERFLOW, "K cap: the table of dropped pairs could not be sized");
@@ -2267,10 +2325,17 @@ extern "C" int sppm_intersect_static(const sppm_sphere* h_spheres, int32_t n_sph
         return fail(SPPM_ERR_INVALID, "sppm_intersect_static: at most " + std::to_string(SPPM_STATIC_MAX_SPHERES) + " spheres fit the static table (got " +
                                           std::to_string(n_spheres) + "); larger scenes go through sppm_create + sppm_intersect");
     if (n > (1ll << 40)) return fail(SPPM_ERR_INVALID, "sppm_intersect_static: more than 2^40 rays");
+    hipStream_t st = (hipStream_t)stream;
+    if (st) {  // the array used is the CURRENT device's copy: a stream of another GPU would be handed the wrong address
+        int cur = -1;
+        hipDevice_t sdev = -1;
+        HIPCHK(hipGetDevice(&cur));
+        HIPCHK(hipStreamGetDevice(st, &sdev));
+        if ((int)sdev != cur) return fail(SPPM_ERR_INVALID, "sppm_intersect_static: the stream belongs to device " + std::to_string((int)sdev) + ", the current device is " + std::to_string(cur));
+    }
     unsigned char* ptr = nullptr;
     int rc = static_scratch(&ptr);
     if (rc) return rc;
-    hipStream_t st = (hipStream_t)stream;
     HIPCHK(hipMemsetAsync(ptr, 0, SCRATCH_HEAD, st));  // the array keeps the last call's contents: the counter must start at zero
     for (int first = 0; first < n_spheres; first += SCRATCH_CHUNK) {
         SphereChunk chunk;

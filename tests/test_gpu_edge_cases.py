@@ -93,3 +93,11 @@ def test_camera_that_sees_no_diffuse_surface(rule):
     assert ctx.counters()["updates"] == orc.counters()["updates"]
     _same(ctx.resolve(1, M).cpu().numpy(), orc.resolve(1, M), "image")
     ctx.close()
+
+
+def test_per_pass_rule_with_hitpoint_ownership_is_refused():
+    """update_rule 1 shards photons, not hitpoints: a share of the hitpoints per rank (tile_stride > 1) would leave the
+    imported sums of the hitpoints a rank does not own in place for the next pass -- refused at creation."""
+    from raytracer_amd import capi
+    with pytest.raises(capi.SppmError, match="update_rule 1 keeps all hitpoints"):
+        sppm.SppmContext(sppm.make_config(64, 48, photons_per_pass=1000, update_rule=1, tile_first=0, tile_stride=2))

@@ -99,12 +99,64 @@ def test_cap_switched_off_is_the_uncapped_set():
     assert res["capped"]["n"].sum() < res["uncapped"]["n"].sum()
 
 
-def test_cap_with_the_per_pass_rule_is_refused():
-    ctx = sppm.SppmContext(sppm.make_config(64, 48, photons_per_pass=5000, gather_max=50, update_rule=1))
-    ctx.eye_pass(0)
-    with pytest.raises(capi.SppmError, match="update_rule 0"):
-        ctx.photon_pass(0, 5000)
+@pytest.mark.parametrize("K,batches,mode", [(3, 1, "tiles"), (8, 3, "tiles"), (3, 2, "simple")])
+def test_capped_search_under_the_per_pass_rule_matches_oracle(K, batches, mode, monkeypatch):
+    """src/stochastic_ppm.h:425-427 hand gahter_max_photon_num to the same SearchNearest: update_rule 1 with a binding K.
+    Accepted pairs, fixed-point deposits, state and image equal the oracle's bit for bit (the oracle's capped per-pass
+    rule is pinned by the compiled file's runs ref_pp_64x48_k8 / ref_pp_320x240_k100)."""
+    W, H, M, passes = 64, 48, 20000, 3
+    if mode == "simple":
+        monkeypatch.setenv("SPPM_GATHER_TILES", "0")
+    ctx = sppm.SppmContext(sppm.make_config(W, H, photons_per_pass=M, gather_max=K, update_rule=1))
+    orc = ol.Oracle(ol.make_params(W, H, sampler=1, math=1, photons_per_pass=M, gather_max=K, rule=1), ol.make_spheres(CORNELL_SPHERES))
+    for i in range(passes):
+        ctx.eye_pass(i); orc.eye_pass(i)
+        tap = orc.photon_pass(i, M, tap=True, acc_cap=8_000_000)
+        ok = _okeys(tap)[tap["acc_rec"]]
+        order = np.lexsort((tap["acc_pix"], ok))
+        got_k, got_p = [], []
+        per = M // batches
+        for b in range(batches):
+            first, count = b * per, (per if b + 1 < batches else M - b * per)
+            ctx.trace(i, first, count)
+            ctx.accept_tap(8_000_000)
+            ctx.gather()
+            ak, ap = ctx.accepted()
+            ctx.accept_tap(0)
+            got_k.append(ak); got_p.append(ap)
+        ak, ap = np.concatenate(got_k), np.concatenate(got_p)
+        o2 = np.lexsort((ap, ak))
+        _same(ak[o2], ok[order], f"pass {i} accepted keys")
+        _same(ap[o2], tap["acc_pix"][order], f"pass {i} accepted image indices")
+        dep, flag = orc.deposits()
+        assert flag == 0
+        _same(ctx.export_deposits().cpu().numpy().T, dep, f"pass {i} deposits")
+        ctx.end_pass(); orc.end_pass()
+        s, o = ctx.hitpoints(), orc.state()
+        for k in ("n", "r2", "flux"):
+            _same(s[k], o[k], f"pass {i} state {k}")
+        _same(ctx.resolve(i, M).cpu().numpy(), orc.resolve(i, M), f"pass {i} image")
+    ctx.check()
+    c = ctx.counters()
+    assert c["cap_queries"] > 0 and c["cap_dropped_pairs"] > 0, c   # the cap acted
     ctx.close()
+
+
+def test_cap_filter_skips_the_search_where_no_query_can_overflow():
+    """K below the number of hitpoints, but above what any photon hit can see within the search radius: the count grid of
+    sppm_cap.hpp (k_cap_filter) lets no photon hit through, no tree is walked, and the result is the uncapped one."""
+    W, H, M = 64, 48, 20000
+    res = {}
+    for tag, kw in (("filtered", dict(gather_max=2000)), ("uncapped", dict(gather_max=1 << 40))):
+        ctx = sppm.SppmContext(sppm.make_config(W, H, photons_per_pass=M, gather_radius2=4.0, **kw))
+        for i in range(2):
+            ctx.eye_pass(i); ctx.photon_pass(i, M)
+        ctx.check()
+        res[tag] = (ctx.hitpoints(), ctx.counters())
+        ctx.close()
+    assert res["filtered"][1]["cap_queries"] == 0 and res["filtered"][1]["cap_dropped_pairs"] == 0
+    for k in ("n", "r2", "flux"):
+        _same(res["filtered"][0][k], res["uncapped"][0][k], k)
 
 
 @pytest.mark.parametrize("tag", ["64x48_k3", "64x48_k8", "320x240_k100"])

@@ -59,6 +59,34 @@ def test_static_entry_point_equals_sppm_intersect_twice():
         assert got_n == int((ref_id >= 0).sum()) and got_n > 0
 
 
+def test_static_entry_point_allocates_nothing_and_handles_300_spheres():
+    """A scene near the upper end of the static table (300 of 512 spheres: eight upload launches) against sppm_intersect,
+    which also takes the brute-force path up to 512 spheres, so equal-distance ties resolve alike; and the device's free
+    memory (hipMemGetInfo) is the same before and after a call: the entry point allocates nothing."""
+    import torch
+    table = scene.synthetic_spheres(300 - 7)  # (the generator adds the seven spheres of the box)
+    assert 256 < len(table) <= 512
+    rays = _rays(50_000, 5)
+    ref_id, ref_hit = _existing(table, rays)
+    _static(table, rays[:64])  # a first call on this device (it resolves the array's address)
+    L = capi.lib()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    d_rays = torch.from_numpy(rays).to(dev)
+    n = rays.shape[0]
+    ids = torch.full((n,), -7, dtype=torch.int32, device=dev)
+    hit = torch.full((n, 7), -7.0, dtype=torch.float64, device=dev)
+    arr = sppm._sphere_array(table)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info(dev)[0]
+    capi.check(L.sppm_intersect_static(arr, len(arr), d_rays.data_ptr(), n, ids.data_ptr(), hit.data_ptr(), None, C.c_void_p(stream)))
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info(dev)[0]
+    assert free1 == free0, f"free device memory changed by {free0 - free1} bytes across the call"
+    assert np.array_equal(ids.cpu().numpy(), ref_id)
+    assert np.array_equal(hit.cpu().numpy().view(np.uint64), ref_hit.view(np.uint64))
+
+
 def test_static_entry_point_rejects_large_scenes():
     import torch
     L = capi.lib()
