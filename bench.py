@@ -255,7 +255,7 @@ def measured_counters(width, height, photons, rule, steps):
     return t
 
 
-def k_cap_enforced(width, height, photons, table, torch, passes=2):
+def k_cap_enforced(width, height, photons, table, torch, passes=3):
     """The timed renders run UNCAPPED (gather_max out of reach; config.gather_max says so).  BASELINE config 2 passes
     K = 10000 to the kd search, which acts on a few percent of the photon hits at 1080p: this measures the same render
     with the cap ENFORCED exactly (sppm_config.check_gather_max = 0, raytracer_amd/csrc/sppm_cap.hpp) over `passes`
@@ -264,17 +264,22 @@ def k_cap_enforced(width, height, photons, table, torch, passes=2):
     ctx = sppm.SppmContext(sppm.make_config(width, height, photons_per_pass=photons, gather_max=10000), spheres=table)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    per_pass = []
     for i in range(passes):
+        t1 = time.perf_counter()
         ctx.eye_pass(i); ctx.photon_pass(i, photons); ctx.end_pass()
+        torch.cuda.synchronize()
+        per_pass.append(1e3 * (time.perf_counter() - t1))
     ctx.check()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     c = ctx.counters()
     ctx.close()
-    return {"gather_max": 10000, "passes": passes, "photons_per_s": passes * photons / dt, "ms_per_pass": 1e3 * dt / passes,
+    return {"gather_max": 10000, "passes": passes, "photons_per_s": passes * photons / dt, "ms_per_pass": 1e3 * dt / passes, "ms_each_pass": per_pass,
             "photon_hits": c["records"], "photon_hits_capped": c["cap_queries"], "pairs_withheld": c["cap_dropped_pairs"], "updates": c["updates"],
-            "note": "per-photon rule with the reference's K cap enforced bit-exactly (tests/test_gpu_k_cap.py): host-built kd order + one search lane "
-                    "per photon hit; a fidelity mode, not the timed path"}
+            "note": "per-photon rule with the reference's K cap enforced bit-exactly (tests/test_gpu_k_cap.py): host-built kd order (about 0.37 s of each pass, "
+                    "std::sort as in the reference) + one search lane and one heap of K + 1 entries per photon hit that can see more than K hitpoints; the "
+                    "first pass also allocates the heaps; a fidelity mode, not the timed path"}
 
 
 def image_quality():
@@ -402,7 +407,9 @@ def report(args, world, rule, r, table_name):
         out["roofline_trace"]["note"] = "rank 0; rays cast by photon tracing; the flop figure prices a ray at the Cornell scene's 219 flop (a grid walk tests fewer spheres per ray than brute force, so this is not a flop count for this scene)"
     if world > 1:
         ex = r["exchange_ms"]
-        out["rccl_ranks"] = world
+        import torch.distributed as dist
+        out["rccl_ranks"] = dist.get_world_size()   # from the process group, not from the command line
+        out["collective_backend"] = dist.get_backend()
         out["exchanged_bytes_per_pass_per_rank"] = r["exchanged_bytes"] / max(1, args.steps)
         out["stage_ms"] = {"trace_launch_avg": t_ns / 1e6 / t_launch, "exchange_avg": sum(ex) / len(ex) if ex else None, "gather_launch_avg": g_ns / 1e6 / g_launch,
                            "note": "rank 0; trace overlaps the gather on its own streams; exchange = " + ("export + all-reduce + import of the deposits, per pass, on the context's stream" if rule == 1 else
@@ -443,9 +450,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch N > 1 through torch.distributed.run (one rank per GPU)")
+    if args.gpus != world:  # no retry, no re-exec: a mismatch is the launcher's to fix
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}: launch N > 1 as `python -m torch.distributed.run --nnodes=1 "
+                 f"--nproc-per-node {args.gpus} --master-addr 127.0.0.1 ... bench.py --gpus {args.gpus} ...` (one rank per GPU)")
     # SPPM_BENCH_BACKEND=gloo rehearses the N > 1 path on a box with fewer GPUs than ranks (ranks share devices)
     backend = os.environ.get("SPPM_BENCH_BACKEND", "nccl")
     local = local % max(1, torch.cuda.device_count()) if backend != "nccl" else local
@@ -455,6 +462,10 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend)
+        if dist.get_world_size() != args.gpus:
+            sys.exit(f"bench.py: the process group has {dist.get_world_size()} ranks, --gpus says {args.gpus}")
+        if rank == 0:
+            print(f"[bench] process group: backend {dist.get_backend()}, {dist.get_world_size()} ranks, one per GPU", file=sys.stderr, flush=True)
 
     def barrier():
         if world > 1:

@@ -34,7 +34,7 @@ __device__ __forceinline__ int cap_coord(double x, double o, double inv_c, int n
     return i > n - 1 ? n - 1 : i;
 }
 __global__ void __launch_bounds__(256) k_cap_filter(RecArrays rec, const unsigned long long* __restrict__ rec_count, CapGrid g, double reach, long long K,
-                                                    uint32_t* __restrict__ surv, unsigned long long* __restrict__ n_surv)
+                                                    uint32_t* __restrict__ surv, uint32_t* __restrict__ surv_cell, unsigned long long* __restrict__ n_surv)
 {
     const long long slots = min((long long)*rec_count, (long long)rec.cap);
     const long long cap = rec.cap;
@@ -48,15 +48,19 @@ __global__ void __launch_bounds__(256) k_cap_filter(RecArrays rec, const unsigne
         for (int iz = z0; iz <= z1; iz++)
             for (int iy = y0; iy <= y1; iy++)
                 for (int ix = x0; ix <= x1; ix++) sum += (long long)g.cnt[((size_t)iz * g.ny + iy) * g.nx + ix];
-        if (sum > K) surv[atomicAdd(n_surv, 1ull)] = (uint32_t)r;
+        if (sum > K) {  // survivors carry their own cell, so that the search can take them in spatial order (cap_search sorts on it)
+            const unsigned long long slot = atomicAdd(n_surv, 1ull);
+            surv[slot] = (uint32_t)r;
+            surv_cell[slot] = (uint32_t)(((size_t)cap_coord(qz, g.oz, g.inv_c, g.nz) * g.ny + cap_coord(qy, g.oy, g.inv_c, g.ny)) * g.nx + cap_coord(qx, g.ox, g.inv_c, g.nx));
+        }
     }
 }
 
 struct CapParams {
     const uint32_t* surv; long long n_surv;  // the photon hits (record slots) the cap can act on (k_cap_filter)
-    const int32_t* kd; int n;          // the reference's node_values_ after CreateKDtree: hitpoint slots, sorted range by range
+    const double4* kd; int n;          // the reference's node_values_ after CreateKDtree, sorted range by range: position and (w) hitpoint slot
     double R0; long long K;            // gather_photon_radius (squared), gahter_max_photon_num
-    double* heap_d2; int32_t* heap_pix; long long heap_stride; int lanes;  // one heap of K+1 entries per lane
+    double2* heap; long long heap_stride; int lanes;  // one heap of K+1 entries (x: squared distance, y: hitpoint slot) per lane
     Veto veto; unsigned long long* veto_n; unsigned long long veto_cap;      // table and fill; entries beyond veto_cap are counted, not stored
     unsigned long long* stat;          // [0] queries whose cap acted, [1] nodes visited, [2] largest heap fill
     Own own;
@@ -71,45 +75,46 @@ __device__ __forceinline__ void veto_put(const CapParams& cp, unsigned long long
     }
 }
 
-// std::push_heap / std::pop_heap of libstdc++ (bits/stl_heap.h: __push_heap, __adjust_heap) on (d2, pix), ordered by d2
-__device__ __forceinline__ void cap_heap_push(double* hd, int32_t* hx, long long n /* size before */, double d2, int32_t pix)
+// std::push_heap / std::pop_heap of libstdc++ (bits/stl_heap.h: __push_heap, __adjust_heap) on (d2, pix), ordered by d2.
+// An entry is one 16-byte word: a move is one load and one store.
+__device__ __forceinline__ void cap_heap_push(double2* h, long long n /* size before */, double d2, int32_t pix)
 {
     long long hole = n;
     while (hole > 0) {
         const long long par = (hole - 1) / 2;
-        const double pd = hd[par];
-        if (!(pd < d2)) break;
-        hd[hole] = pd; hx[hole] = hx[par];
+        const double2 p = h[par];
+        if (!(p.x < d2)) break;
+        h[hole] = p;
         hole = par;
     }
-    hd[hole] = d2; hx[hole] = pix;
+    h[hole] = make_double2(d2, (double)pix);
 }
 // removes the top; n = size before; the caller has read the top already
-__device__ __forceinline__ void cap_heap_pop(double* hd, int32_t* hx, long long n)
+__device__ __forceinline__ void cap_heap_pop(double2* h, long long n)
 {
     const long long len = n - 1;  // the last element becomes `value`, the heap [0, len) gets a hole at the top
     if (len <= 0) return;
-    const double vd = hd[len]; const int32_t vx = hx[len];
+    const double2 v = h[len];
     long long hole = 0, child = 0;
     while (child < (len - 1) / 2) {
         child = 2 * (child + 1);
-        if (hd[child] < hd[child - 1]) child--;
-        hd[hole] = hd[child]; hx[hole] = hx[child];
+        const double2 a = h[child], b = h[child - 1];
+        if (a.x < b.x) { child--; h[hole] = b; } else h[hole] = a;
         hole = child;
     }
     if ((len & 1) == 0 && child == (len - 2) / 2) {
         child = 2 * (child + 1);
-        hd[hole] = hd[child - 1]; hx[hole] = hx[child - 1];
+        h[hole] = h[child - 1];
         hole = child - 1;
     }
     while (hole > 0) {  // __push_heap(first, hole, 0, value)
         const long long par = (hole - 1) / 2;
-        const double pd = hd[par];
-        if (!(pd < vd)) break;
-        hd[hole] = pd; hx[hole] = hx[par];
+        const double2 p = h[par];
+        if (!(p.x < v.x)) break;
+        h[hole] = p;
         hole = par;
     }
-    hd[hole] = vd; hx[hole] = vx;
+    h[hole] = v;
 }
 
 #define CAP_STACK 96
@@ -117,8 +122,7 @@ __global__ void __launch_bounds__(64) k_cap_search(HpArrays hp, RecArrays rec, c
 {
     const int lane_id = blockIdx.x * blockDim.x + threadIdx.x;
     if (lane_id >= cp.lanes) return;
-    double* hd = cp.heap_d2 + (long long)lane_id * cp.heap_stride;
-    int32_t* hx = cp.heap_pix + (long long)lane_id * cp.heap_stride;
+    double2* heap = cp.heap + (long long)lane_id * cp.heap_stride;
     const long long cap = rec.cap, P = hp.P;
     const double thr0 = cp.R0 * 0.01;
     unsigned long long n_capped = 0, n_nodes = 0, max_fill = 0;
@@ -155,9 +159,10 @@ __global__ void __launch_bounds__(64) k_cap_search(HpArrays hp, RecArrays rec, c
             const bool shadow = (f & F_SHADOW) != 0;
             const int depth = f & 0xFF;
             const int mid = begin + (end - begin) / 2;
-            const int pix = cp.kd[mid];
+            const double4 node = cp.kd[mid];
+            const int pix = (int)node.w;
             n_nodes++;
-            const d3 np = mk(hp.pos[pix], hp.pos[P + pix], hp.pos[2 * P + pix]);
+            const d3 np = mk(node.x, node.y, node.z);
             const int axis = depth % 3;
             const double delta = axis == 0 ? q.x - np.x : (axis == 1 ? q.y - np.y : q.z - np.z);
             const d3 dir = np - q;
@@ -166,14 +171,15 @@ __global__ void __launch_bounds__(64) k_cap_search(HpArrays hp, RecArrays rec, c
             const bool pass0 = d2 < cp.R0 && fabs(dt) <= thr0;
             int drop = -1; double drop_d2 = 0.0;  // a hitpoint the uncapped search holds and this one does not
             if (!shadow && d2 < B && fabs(dt) <= B * 0.01) {
-                cap_heap_push(hd, hx, nh, d2, pix);
+                cap_heap_push(heap, nh, d2, pix);
                 nh++;
                 if ((unsigned long long)nh > max_fill) max_fill = (unsigned long long)nh;
                 if (nh > cp.K) {
-                    drop = hx[0]; drop_d2 = hd[0];
-                    cap_heap_pop(hd, hx, nh);
+                    const double2 top = heap[0];
+                    drop = (int)top.y; drop_d2 = top.x;
+                    cap_heap_pop(heap, nh);
                     nh--;
-                    B = hd[0];
+                    B = heap[0].x;
                     capped = true;
                 }
             } else if (pass0 && (shadow || capped)) { drop = pix; drop_d2 = d2; }

@@ -31,6 +31,7 @@
 #include <random>
 #include <string>
 #include <thread>
+#include <chrono>
 #include <type_traits>
 #include <vector>
 
@@ -162,11 +163,11 @@ struct sppm_ctx {
     // K cap of the reference's search (sppm_cap.hpp): the reference's hitpoint vector in the order its tree leaves it
     // (host), the same on the device, one heap per search lane, the table of dropped pairs the gathers consult
     std::vector<int32_t> kd_order; std::vector<uint8_t> kd_listed; int kd_pass, kd_fallback;
-    int32_t* d_kd; int64_t kd_cap;
+    double4* d_kd; int64_t kd_cap;
     // the K cap's filter (sppm_cap.hpp): hitpoint counts on a coarse grid, the photon hits whose bound exceeds K
     uint32_t* d_cap_cnt; int64_t cap_cnt_cap; CapGrid cap_grid; uint32_t* d_cap_surv; int64_t cap_surv_cap; unsigned long long* d_cap_nsurv;
     uint64_t cap_filtered;  // photon hits that passed the filter so far
-    double* d_heap_d2; int32_t* d_heap_pix; int64_t heap_cap_d, heap_cap_x;
+    double2* d_heap; int64_t heap_cap; uint32_t *d_cap_cell, *d_cap_surv_s, *d_cap_cell_s; int64_t cap_cell_cap; void* d_cap_sort_tmp; size_t cap_sort_bytes;
     unsigned long long* d_veto_tab; int64_t veto_entries; unsigned long long *d_veto_n, *d_cap_stat;
     Veto veto_dev;  // what the gathers get: n == nullptr while the cap cannot act
     uint64_t cap_queries, cap_capped, cap_nodes, cap_vetoes, cap_max_fill;
@@ -624,8 +625,9 @@ extern "C" int sppm_destroy(sppm_ctx* c)
     if (c->d_cap_cnt) hipFree(c->d_cap_cnt);
     if (c->d_cap_surv) hipFree(c->d_cap_surv);
     if (c->d_cap_nsurv) hipFree(c->d_cap_nsurv);
-    if (c->d_heap_d2) hipFree(c->d_heap_d2);
-    if (c->d_heap_pix) hipFree(c->d_heap_pix);
+    if (c->d_heap) hipFree(c->d_heap);
+    if (c->d_cap_cell) { hipFree(c->d_cap_cell); hipFree(c->d_cap_surv_s); hipFree(c->d_cap_cell_s); }
+    if (c->d_cap_sort_tmp) hipFree(c->d_cap_sort_tmp);
     if (c->d_veto_tab) hipFree(c->d_veto_tab);
     if (c->d_veto_n) { hipFree(c->d_veto_n); hipFree(c->d_cap_stat); }
     if (c->d_u_eye) hipFree(c->d_u_eye);
@@ -1623,6 +1625,7 @@ static int cap_build_tree(sppm_ctx* c)
     const int64_t P = c->P;
     HIPCHK(hipStreamSynchronize(c->eye_stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    const auto t_build = std::chrono::steady_clock::now();
     std::vector<int32_t> valid((size_t)P);
     std::vector<double> pos((size_t)P * 3);
     HIPCHK(hipMemcpy(valid.data(), c->hp.valid, (size_t)P * 4, hipMemcpyDeviceToHost));
@@ -1641,7 +1644,14 @@ static int cap_build_tree(sppm_ctx* c)
     const int n = (int)c->kd_order.size();
     cap_sort_range(c->kd_order.data(), pos.data(), P, 0, n, 0, 4);
     if (grow(c, &c->d_kd, &c->kd_cap, std::max<int64_t>(n, 1))) return SPPM_ERR_HIP;
-    HIPCHK(hipMemcpy(c->d_kd, c->kd_order.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    {   // a node as the walk reads it: one 32-byte word (position, hitpoint slot)
+        std::vector<double4> nodes((size_t)std::max(n, 1));
+        for (int i = 0; i < n; i++) {
+            const size_t h = (size_t)c->kd_order[(size_t)i];
+            nodes[(size_t)i] = make_double4(pos[h], pos[(size_t)P + h], pos[2 * (size_t)P + h], (double)c->kd_order[(size_t)i]);
+        }
+        HIPCHK(hipMemcpy(c->d_kd, nodes.data(), (size_t)n * sizeof(double4), hipMemcpyHostToDevice));
+    }
     {   // the filter's grid: the tree's hitpoints counted in cells of half the search radius (at most 2^22 cells)
         double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
         for (int i = 0; i < n; i++)
@@ -1670,6 +1680,7 @@ static int cap_build_tree(sppm_ctx* c)
         g.cnt = c->d_cap_cnt;
     }
     c->kd_pass = c->last_eye_pass;
+    if (getenv("SPPM_DEBUG")) fprintf(stderr, "[sppm] K cap: tree of %d hitpoints built on the host in %.1f ms\n", n, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_build).count());
     return 0;
 }
 // the capped search of every record in the current buffer; leaves the dropped pairs in the Veto table
@@ -1684,22 +1695,49 @@ static int cap_search(sppm_ctx* c)
     if (K < 0) return fail(SPPM_ERR_INVALID, "gather_max is negative");
     // the photon hits the cap can act on at all (k_cap_filter): usually a few percent, often none
     if (grow(c, &c->d_cap_surv, &c->cap_surv_cap, c->rec_u.cap)) return SPPM_ERR_HIP;
+    if (c->cap_cell_cap < c->rec_u.cap) {
+        if (c->d_cap_cell) { hipFree(c->d_cap_cell); hipFree(c->d_cap_surv_s); hipFree(c->d_cap_cell_s); c->d_cap_cell = nullptr; }
+        HIPCHK(hipMalloc((void**)&c->d_cap_cell, (size_t)c->rec_u.cap * 4));
+        HIPCHK(hipMalloc((void**)&c->d_cap_surv_s, (size_t)c->rec_u.cap * 4));
+        HIPCHK(hipMalloc((void**)&c->d_cap_cell_s, (size_t)c->rec_u.cap * 4));
+        c->cap_cell_cap = c->rec_u.cap;
+    }
     if (!c->d_cap_nsurv) HIPCHK(hipMalloc((void**)&c->d_cap_nsurv, 8));
     HIPCHK(hipMemsetAsync(c->d_cap_nsurv, 0, 8, st));
     const double reach = std::sqrt(c->cfg.gather_radius2) * (1.0 + 1e-9) + 1e-9;
-    hipLaunchKernelGGL(k_cap_filter, dim3(1024), dim3(256), 0, st, c->rec_u, c->d_rec_count, c->cap_grid, reach, (long long)K, c->d_cap_surv, c->d_cap_nsurv);
+    hipLaunchKernelGGL(k_cap_filter, dim3(1024), dim3(256), 0, st, c->rec_u, c->d_rec_count, c->cap_grid, reach, (long long)K, c->d_cap_surv, c->d_cap_cell, c->d_cap_nsurv);
     HIPCHK(hipGetLastError());
     unsigned long long n_surv = 0;
     HIPCHK(hipMemcpyAsync(&n_surv, c->d_cap_nsurv, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     c->cap_filtered += n_surv;
     if (n_surv == 0) return 0;  // no photon hit of this batch can see more than K hitpoints: the cap cannot act
+    // Photon hits of one wavefront should walk the same part of the tree (their node reads then fall into the same
+    // cache lines and their walks are about equally long): take the survivors cell by cell.
+    {
+        size_t need = 0;
+        if (rocprim::radix_sort_pairs(nullptr, need, c->d_cap_cell, c->d_cap_cell_s, c->d_cap_surv, c->d_cap_surv_s, (size_t)n_surv, 0, 32, st) != hipSuccess)
+            return fail(SPPM_ERR_HIP, "K cap: sort size query failed");
+        if (need > c->cap_sort_bytes) {
+            if (c->d_cap_sort_tmp) hipFree(c->d_cap_sort_tmp);
+            c->d_cap_sort_tmp = nullptr; c->cap_sort_bytes = 0;
+            HIPCHK(hipMalloc(&c->d_cap_sort_tmp, need));
+            c->cap_sort_bytes = need;
+        }
+        size_t bytes = c->cap_sort_bytes;
+        HIPCHK(rocprim::radix_sort_pairs(c->d_cap_sort_tmp, bytes, c->d_cap_cell, c->d_cap_cell_s, c->d_cap_surv, c->d_cap_surv_s, (size_t)n_surv, 0, 32, st));
+    }
+    // One heap of K + 1 entries per photon hit in flight.  The walk is a chain of dependent reads, so the more of them
+    // are in flight the better: up to a quarter of the free device memory (SPPM_CAP_HEAP_MB overrides), 64 GiB at most.
     const int64_t stride = K + 1;
-    const int64_t budget = env_i64("SPPM_CAP_HEAP_MB", 4096) << 20;
-    int64_t lanes = std::min<int64_t>(65536, std::max<int64_t>(64, budget / (12 * stride)));
+    size_t mem_free = 0, mem_total = 0;
+    HIPCHK(hipMemGetInfo(&mem_free, &mem_total));
+    const int64_t held = c->heap_cap * (int64_t)sizeof(double2);
+    const int64_t budget = env_i64("SPPM_CAP_HEAP_MB", std::min<int64_t>(65536, (int64_t)(((int64_t)mem_free + held) / 4) >> 20)) << 20;
+    int64_t lanes = std::min<int64_t>(1 << 20, std::max<int64_t>(64, budget / ((int64_t)sizeof(double2) * stride)));
     lanes = std::min<int64_t>(lanes, ((int64_t)n_surv + 63) / 64 * 64);  // heaps for the photon hits that need one
     lanes = std::max<int64_t>(64, lanes / 64 * 64);
-    if (grow(c, &c->d_heap_d2, &c->heap_cap_d, lanes * stride) || grow(c, &c->d_heap_pix, &c->heap_cap_x, lanes * stride)) return SPPM_ERR_HIP;
+    if (grow(c, &c->d_heap, &c->heap_cap, lanes * stride)) return SPPM_ERR_HIP;
     if (!c->d_veto_n) { HIPCHK(hipMalloc((void**)&c->d_veto_n, 8)); HIPCHK(hipMalloc((void**)&c->d_cap_stat, 32)); }
     for (int attempt = 0;; attempt++) {
         if (!c->d_veto_tab) {
@@ -1711,9 +1749,9 @@ static int cap_search(sppm_ctx* c)
         HIPCHK(hipMemsetAsync(c->d_cap_stat, 0, 32, st));
         CapParams cp;
         memset(&cp, 0, sizeof cp);
-        cp.surv = c->d_cap_surv; cp.n_surv = (long long)n_surv;
+        cp.surv = c->d_cap_surv_s; cp.n_surv = (long long)n_surv;
         cp.kd = c->d_kd; cp.n = n; cp.R0 = c->cfg.gather_radius2; cp.K = K;
-        cp.heap_d2 = c->d_heap_d2; cp.heap_pix = c->d_heap_pix; cp.heap_stride = stride; cp.lanes = (int)lanes;
+        cp.heap = c->d_heap; cp.heap_stride = stride; cp.lanes = (int)lanes;
         cp.veto.tab = c->d_veto_tab; cp.veto.mask = (unsigned long long)c->veto_entries - 1ull; cp.veto.n = c->d_veto_n;
         cp.veto_n = c->d_veto_n; cp.veto_cap = (unsigned long long)c->veto_entries / 2ull;
         cp.stat = c->d_cap_stat; cp.own = own_of(c);
@@ -1878,7 +1916,11 @@ extern "C" int sppm_photon_pass(sppm_ctx* c, int32_t pass, int64_t first, int64_
                 last = nb; applied += (uint64_t)nb.count;
             }
         }
-        // the caller is expected to go on with the next pass: its eye pass runs ahead too (eye paths do not depend on photons)
+        // the caller is expected to go on with the next pass: its eye pass runs ahead too (eye paths do not depend on photons).
+        // (Both start where the gather BEFORE this one ends and so run against the small kernels between two gather
+        // kernels.  Holding the tracer, or both, back until those kernels are done was measured in round 3: the window
+        // shrinks to 70 us of kernels, but the next window then waits for the eye pass, which runs 3 ms in the gather's
+        // shadow instead of 0.4 ms -- 249 and 255 M photons/s against 267.)
         if (c->algo == 0 && !c->ahead.empty() && c->ahead.front().pass == pass + 1) { rc = eye_prefetch(c, pass + 1); if (rc) return rc; }
         // gather the current batch
         HIPCHK(hipStreamWaitEvent(c->stream, c->ev_traced[cur.buf], 0));

@@ -38,11 +38,12 @@ def _single(W, H, M, passes):
 _EXCHANGED = {}
 
 
-@pytest.mark.parametrize("exchange,ownership", [("allgather", 1), ("alltoall", 1), ("replicate", 0), ("allgather", 0)])
-def test_two_ranks_equal_one_gpu(tmp_path, exchange, ownership):
-    world, W, H, M_rank, passes = 2, 96, 64, 24000, 3
+@pytest.mark.parametrize("exchange,ownership,world", [("allgather", 1, 2), ("alltoall", 1, 2), ("replicate", 0, 2), ("allgather", 0, 2), ("alltoall", 1, 4)])
+def test_ranks_equal_one_gpu(tmp_path, exchange, ownership, world):
+    """(world 4: the rehearsal of the node run -- four gloo ranks on this one GPU, the ragged all-to-all between all pairs)"""
+    W, H, M_rank, passes = 96, 64, 24000, 3
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    port = 29600 + os.getpid() % 1000 + {"allgather": 0, "replicate": 1, "alltoall": 4}[exchange] + 2 * ownership
+    port = 29600 + os.getpid() % 1000 + {"allgather": 0, "replicate": 1, "alltoall": 4}[exchange] + 2 * ownership + 10 * world
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker_gpu.py"), str(tmp_path), exchange, str(ownership)]
     res = _run(cmd, env)
@@ -59,6 +60,8 @@ def test_two_ranks_equal_one_gpu(tmp_path, exchange, ownership):
             merged[m] = g[k][m]
         a, b = np.ascontiguousarray(merged), np.ascontiguousarray(ref[k])
         assert (a.view(np.uint64) == b.view(np.uint64)).all() if a.dtype.kind == "f" else (a == b).all(), k
+    if world != 2:
+        return
     _EXCHANGED[(exchange, ownership)] = [int(g["exchanged"]) for g in got]
     if ("allgather", 1) in _EXCHANGED and ("alltoall", 1) in _EXCHANGED:
         # sorted by destination, a rank receives only the records near its hitpoints: fewer bytes than the all-gather brings
@@ -66,13 +69,14 @@ def test_two_ranks_equal_one_gpu(tmp_path, exchange, ownership):
         assert min(_EXCHANGED[("alltoall", 1)]) > 0
 
 
-def test_two_ranks_per_pass_rule_equal_one_gpu(tmp_path):
+@pytest.mark.parametrize("world", [2, 4])
+def test_ranks_per_pass_rule_equal_one_gpu(tmp_path, world):
     """north_star's multi-GPU path (ShardedSppm(rule=1)): each rank traces half of every pass's photons and deposits them
     into its copy of all hitpoints, one all-reduce of the 64-bit fixed-point deposits per pass, the same end-of-pass
     update on every rank.  State and image on BOTH ranks equal a single-GPU run of the per-pass rule bit for bit."""
-    world, W, H, M_rank, passes = 2, 96, 64, 24000, 3
+    W, H, M_rank, passes = 96, 64, 24000, 3
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    port = 29900 + os.getpid() % 1000
+    port = 29900 + os.getpid() % 1000 + 10 * world
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker_gpu.py"), str(tmp_path), "allreduce", "0"]
     res = _run(cmd, env)
