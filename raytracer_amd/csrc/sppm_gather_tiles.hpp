@@ -286,6 +286,7 @@ __global__ void __launch_bounds__(256) k_tile_plan(HpArrays hp, const uint32_t* 
                                                    uint32_t* __restrict__ est)
 {
     __shared__ uint32_t s_stack[4][16];
+    __builtin_amdgcn_s_setprio(3);  // (the gather waits for this kernel while the tracer and the eye pass run beside it: as k_deposit_plan)
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int k = blockIdx.x * 4 + wv;
     if (k >= tp.n_owned) return;

@@ -93,8 +93,9 @@ struct sppm_ctx {
     int own_pending;       // spatial ownership: the pixel list is cut out of the first eye pass's Morton order
     hp_key_t *d_hp_keys, *d_hp_keys_out; unsigned long long* d_hp_bb;
     void* d_sort_tmp; size_t sort_tmp_bytes;
-    uint32_t *d_cell_tot, *d_est, *d_items; unsigned long long* d_items_raw; unsigned int* d_item_q; uint8_t* d_n_pieces; unsigned long long* d_est_sum; uint8_t* d_ext_bin; int est_valid;  // d_item_q: [0] items [1] queue head [2..33] per cost class
+    uint32_t *d_est, *d_items; unsigned long long* d_items_raw; unsigned int* d_item_q; uint8_t* d_n_pieces; unsigned long long* d_est_sum; uint8_t* d_ext_bin; int est_valid;  // d_item_q: [0] items [1] queue head [2..33] per cost class
     double split_factor, est_per_photon; int64_t est_range;
+    int64_t batch_min; double batch_growth;  // per-photon rule: first batch and growth of the batches with the photons applied (batch_size)
     double fx_scale;          // per-pass rule: fixed point of the deposits (sppm_deposit.hpp), a power of two
     double cell_factor_dep;   // per-pass rule: cell size of the record grid as a share of the median tile extent
     int64_t dep_chunk;        // per-pass rule: records per work item
@@ -150,7 +151,7 @@ struct sppm_ctx {
     uint32_t *d_cell_cnt, *d_cell_start, *d_cursor, *d_block_sum, *d_total, *d_rec_bucket;  // alias bins[cur]
     // One set of binning tables and sorted records per record buffer: a batch is binned on the tracer's
     // stream right after it was traced, while the gather of the batch before it still runs.
-    struct BinSet { RecArrays rec_s; uint32_t *rec_bucket, *cell_cnt, *cell_start, *cursor, *block_sum, *total; TileGrid g; int binned; } bins[NBUF];
+    struct BinSet { RecArrays rec_s; uint32_t *rec_bucket, *cell_cnt, *cell_start, *cursor, *block_sum, *total, *cell_tot; TileGrid g; int binned; } bins[NBUF];
     // Tile statistics travel to the host one batch late (pinned slots, no stream sync in steady state):
     // they only size the grid and balance the load, never change a result.
     typedef StatSnapshot StatSlot;
@@ -487,6 +488,8 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
     for (int k = 0; k < 3; k++)
         if (hipEventCreateWithFlags(&c->ev_order[k], hipEventDisableTiming) != hipSuccess) { sppm_destroy(c); return fail(SPPM_ERR_HIP, "creating events failed"); }
     // record buffers: one batch of photons, ~2.6 records per photon on the Cornell scene; 8x head room
+    c->batch_min = std::max<int64_t>(64, env_i64("SPPM_BATCH_MIN", 32768));
+    { const char* e = getenv("SPPM_BATCH_GROWTH"); c->batch_growth = e && *e && atof(e) > 0.0 ? atof(e) : 0.5; }
     c->batch_photons = env_i64("SPPM_BATCH_PHOTONS", c->gather_mode ? (1 << 20) : (1 << 18));
     if (c->batch_photons < 1024) c->batch_photons = 1024;
     // a rank of a multi-GPU run keeps the records near its hitpoints out of tile_stride x as many photons
@@ -522,6 +525,8 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
         TRY(dev_alloc(c, &B.rec_bucket, (size_t)cap, false));
         TRY(dev_alloc(c, &B.cell_cnt, (size_t)nb)); TRY(dev_alloc(c, &B.cell_start, (size_t)nb + 1)); TRY(dev_alloc(c, &B.cursor, (size_t)nb));
         TRY(dev_alloc(c, &B.block_sum, (size_t)nb / SCAN_BLOCK + 1)); TRY(dev_alloc(c, &B.total, 1));
+        B.cell_tot = nullptr;
+        if (c->gather_mode && cfg->update_rule != 1) TRY(dev_alloc(c, &B.cell_tot, (size_t)c->table_cap / 4 + 1));  // the plan's summed-area table (k_tile_plan)
     }
     if (!c->gather_mode) for (int b = 1; b < NBUF; b++) c->bins[b] = c->bins[0];
     c->h_rows_n = nullptr; c->ev_rows = nullptr; c->rows_pending = 0; c->rows_cap = 0;
@@ -577,7 +582,7 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
         if (hipStreamSynchronize(c->stream) != hipSuccess) { sppm_destroy(c); return fail(SPPM_ERR_HIP, "sppm_create: stream sync failed"); }
         c->sort_tmp_bytes = 0; c->d_sort_tmp = nullptr; c->order_valid = 0;
         TRY(dev_alloc(c, &c->d_est, (size_t)c->n_owned + 1)); TRY(dev_alloc(c, &c->d_items, (size_t)c->n_owned * 64 + 64, false)); TRY(dev_alloc(c, &c->d_items_raw, (size_t)c->n_owned * 64 + 64, false));
-        TRY(dev_alloc(c, &c->d_cell_tot, (size_t)c->table_cap / 4 + 1)); TRY(dev_alloc(c, &c->d_item_q, 2 + 2 * ITEM_CLASSES)); TRY(dev_alloc(c, &c->d_n_pieces, (size_t)c->n_owned + 1)); TRY(dev_alloc(c, &c->d_est_sum, 1)); TRY(dev_alloc(c, &c->d_ext_bin, (size_t)c->n_owned + 1)); c->est_valid = 0;
+        TRY(dev_alloc(c, &c->d_item_q, 2 + 2 * ITEM_CLASSES)); TRY(dev_alloc(c, &c->d_n_pieces, (size_t)c->n_owned + 1)); TRY(dev_alloc(c, &c->d_est_sum, 1)); TRY(dev_alloc(c, &c->d_ext_bin, (size_t)c->n_owned + 1)); c->est_valid = 0;
         c->split_factor = 4.0; c->est_per_photon = 0.0; c->est_range = 0;
         { const char* e = getenv("SPPM_SPLIT_FACTOR"); if (e && *e) c->split_factor = atof(e); }
         if (c->n_own_pix > 0) {
@@ -1393,6 +1398,15 @@ static int bin_into(sppm_ctx* c, int b, const TileGrid& g, hipStream_t st, bool 
     if (rc) return rc;
     hipLaunchKernelGGL(k_grid_scatter, dim3(bin_blocks), dim3(256), 0, st, c->rec_buf[b], B.rec_s, c->d_rec_count_buf[b], B.rec_bucket, B.cursor, 1,
                        c->cfg.update_rule == 1 ? c->fx_scale : 0.0, c->d_err);  // (rule 1 here: deposit_tiles is the reader)
+    // the per-photon rule's plan reads the records of a region from a summed-area table over the cells: it depends on the
+    // binning alone, so it is made here -- for a batch binned ahead, on the tracer's stream, outside the window between
+    // two gathers (round 3: four launches and ~280 us less in that window)
+    if (B.cell_tot) {
+        hipLaunchKernelGGL(k_cell_totals, dim3(nblk(g.ncells, 256)), dim3(256), 0, st, B.cell_start, g.ncells, g.S, B.cell_tot);
+        hipLaunchKernelGGL(k_sat_axis, dim3(nblk(g.ny * g.nz, 64)), dim3(64), 0, st, B.cell_tot, g.nx, g.ny, g.nz, 0);
+        hipLaunchKernelGGL(k_sat_axis, dim3(nblk(g.nx * g.nz, 64)), dim3(64), 0, st, B.cell_tot, g.nx, g.ny, g.nz, 1);
+        hipLaunchKernelGGL(k_sat_axis, dim3(nblk(g.nx * g.ny, 64)), dim3(64), 0, st, B.cell_tot, g.nx, g.ny, g.nz, 2);
+    }
     HIPCHK(hipGetLastError());
     B.g = g; B.binned = 1;
     return 0;
@@ -1439,11 +1453,7 @@ static int gather_tiles(sppm_ctx* c)
     const double thr_d = c->est_per_photon > 0.0 ? std::max(256.0, mean_est * c->split_factor) : 4.0e9;
     const uint32_t split_thr = (uint32_t)std::min(4.0e9, thr_d);
     HIPCHK(hipMemsetAsync(c->d_item_q, 0, sizeof(unsigned int) * (2 + ITEM_CLASSES), st));
-    hipLaunchKernelGGL(k_cell_totals, dim3(nblk(g.ncells, 256)), dim3(256), 0, st, BS.cell_start, g.ncells, g.S, c->d_cell_tot);
-    hipLaunchKernelGGL(k_sat_axis, dim3(nblk(g.ny * g.nz, 64)), dim3(64), 0, st, c->d_cell_tot, g.nx, g.ny, g.nz, 0);
-    hipLaunchKernelGGL(k_sat_axis, dim3(nblk(g.nx * g.nz, 64)), dim3(64), 0, st, c->d_cell_tot, g.nx, g.ny, g.nz, 1);
-    hipLaunchKernelGGL(k_sat_axis, dim3(nblk(g.nx * g.ny, 64)), dim3(64), 0, st, c->d_cell_tot, g.nx, g.ny, g.nz, 2);
-    hipLaunchKernelGGL(k_tile_plan, dim3(nblk(c->n_owned, 4)), dim3(256), 0, st, c->hp, c->d_cell_tot, tp, split_thr, c->d_items_raw, c->d_n_pieces, c->d_est);
+    hipLaunchKernelGGL(k_tile_plan, dim3(nblk(c->n_owned, 4)), dim3(256), 0, st, c->hp, BS.cell_tot, tp, split_thr, c->d_items_raw, c->d_n_pieces, c->d_est);
     hipLaunchKernelGGL(k_items_hist, dim3(nblk(c->n_owned, 256)), dim3(256), 0, st, c->d_items_raw, c->d_n_pieces, c->n_owned, c->d_item_q);
     hipLaunchKernelGGL(k_items_bases, dim3(1), dim3(64), 0, st, c->d_item_q, c->d_rec_count);
     hipLaunchKernelGGL(k_items_scatter, dim3(nblk(c->n_owned, 256)), dim3(256), 0, st, c->d_items_raw, c->d_n_pieces, c->n_owned, c->d_item_q, c->d_items);
@@ -1801,7 +1811,7 @@ static int64_t batch_size(const sppm_ctx* c, uint64_t applied)
     // Batches grow with the photons already applied: the radii shrink like N^-0.43, so a batch about
     // half as long as the history changes them little while it runs.
     int64_t n = c->batch_photons;
-    if (c->gather_mode && c->cfg.update_rule == 0) n = std::min<int64_t>(n, std::max<int64_t>(32768, (int64_t)(applied / 2)));
+    if (c->gather_mode && c->cfg.update_rule == 0) n = std::min<int64_t>(n, std::max<int64_t>(c->batch_min, (int64_t)((double)applied * c->batch_growth)));
     return n;
 }
 
