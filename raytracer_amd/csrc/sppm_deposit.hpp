@@ -208,7 +208,6 @@ __global__ void __launch_bounds__(256) k_items_count(const unsigned long long* _
                                                      unsigned int* __restrict__ q, const uint8_t* __restrict__ ext_bin, TileStats* __restrict__ st)
 {
     __shared__ unsigned int h[ITEM_CLASSES], eh[64], live;
-    __builtin_amdgcn_s_setprio(3);
     if (threadIdx.x < ITEM_CLASSES) h[threadIdx.x] = 0;
     if (threadIdx.x < 64) eh[threadIdx.x] = 0;
     if (threadIdx.x == 0) live = 0;
@@ -232,7 +231,6 @@ __global__ void __launch_bounds__(256) k_items_place(const unsigned long long* _
                                                      const unsigned long long* __restrict__ counters, StatSnapshot* __restrict__ out)
 {
     __shared__ unsigned int h[ITEM_CLASSES], base[ITEM_CLASSES];
-    __builtin_amdgcn_s_setprio(3);
     if (threadIdx.x < ITEM_CLASSES) h[threadIdx.x] = 0;
     __syncthreads();
     const int k = blockIdx.x * blockDim.x + threadIdx.x;

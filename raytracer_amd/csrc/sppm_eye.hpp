@@ -238,8 +238,6 @@ __device__ __forceinline__ void eye_pixel(const DevScene& sc, const EyeParams& e
 template <int GRID>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EYE_WAVES, EYE_WAVES))) k_eye_pass(DevScene sc, EyeParams ep, HpArrays hp, HpArrays out, unsigned long long* __restrict__ counters)
 {
-    // (run ahead, beside the gather of the pass before: the plan of the next gather waits for these hitpoints)
-    __builtin_amdgcn_s_setprio(2);
     STAGE_SCENE_T(sc, GRID);
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int P = ep.W * ep.H;

@@ -68,7 +68,6 @@ __device__ __forceinline__ double undo_ord_d(unsigned long long o)
 // bounding box of the valid hitpoints among pix[0..n): bb[0..2] = min, bb[3..5] = max (ordered ints)
 __global__ void k_hp_bbox(HpArrays hp, const int32_t* __restrict__ pix, int n, unsigned long long* __restrict__ bb)
 {
-    __builtin_amdgcn_s_setprio(2);
     const double BIG = 1e300;
     double lo[3] = {BIG, BIG, BIG}, hi[3] = {-BIG, -BIG, -BIG};
     const int P = hp.P;
@@ -117,7 +116,6 @@ typedef uint32_t hp_key_t;
 __global__ void k_hp_sortkeys(HpArrays hp, const int32_t* __restrict__ pix, int n, const unsigned long long* __restrict__ bb,
                               hp_key_t* __restrict__ keys)
 {
-    __builtin_amdgcn_s_setprio(2);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int p = pix[i], P = hp.P;

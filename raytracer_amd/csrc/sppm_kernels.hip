@@ -69,8 +69,6 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 // NBUF-th pass its kernels sat behind a 4-10 ms tracer launch (profiles/r02_pass_gaps_before.txt: one gap in three
 // of 1.5-7 ms).  So: context, eye, and TWO tracer streams that the buffers of the ring take in turn (NBUF is even).
 #define NTS 2
-#define NV 3    // views of what an eye pass writes: the one the gather reads and up to two made ahead
-#define NORD 4  // tile orders: one per view and one being made
 #define TSTREAM(c, b) ((c)->tstream[(b) % NTS])
 struct sppm_ctx {
     sppm_config cfg;
@@ -108,36 +106,26 @@ struct sppm_ctx {
     double flux_scale;
     std::vector<void*> allocs;
     HpArrays hp;       // the current view (= view[cur_view])
-    // What an eye pass writes (hitpoint geometry, valid flags, direct term, tile order, bounding box) exists NV
-    // times: the eye passes of the passes after this one fill the other views on their own stream while the gather of
-    // pass i still reads this one (one pass ahead; two under the per-pass rule, where the plan of pass i+1's deposit is
-    // made during pass i's and needs the hitpoints of i+1 by then).  Radii, counts and flux are shared (an eye pass only
-    // initialises them for pixels that find their first hitpoint, which nothing else touches until then).
-    HpArrays view[NV]; uint8_t* d_near_v[NV]; uint8_t* d_near; int cur_view;
-    // The tile order (and the bounding box made with it) of an eye pass, in a ring of NORD buffers (in use, made
-    // ahead, being made); view_chain[v]: the buffer of the eye pass that wrote view v.  (Using the order of the pass
+    // What an eye pass writes (hitpoint geometry, valid flags, direct term, tile order, bounding box) exists
+    // twice: the eye pass of pass i+1 fills the other view on its own stream while the gather of pass i still
+    // reads this one.  Radii, counts and flux are shared (an eye pass only initialises them for new pixels).
+    HpArrays view[2]; uint8_t* d_near_v[2]; uint8_t* d_near; int cur_view;
+    // The tile order (and the bounding box made with it) of an eye pass, in a ring of three buffers (in use, made
+    // last, being made); view_chain[v]: the buffer of the eye pass that wrote view v.  (Using the order of the pass
     // BEFORE, so that the sort chain need not finish between two gathers, was tried: any permutation is a valid order,
     // but the ~5 % of the pixels that look through the glass sphere land somewhere else every pass, their tiles of a
     // stale order are scattered over the scene, and the gather took four times as long.)
-    int32_t* d_order_r[NORD]; unsigned long long* d_hp_bb_r[NORD]; hipEvent_t ev_order[NORD];
-    int chain_n, view_chain[NV];
-    hipStream_t eye_stream; hipEvent_t ev_eye_go;
-    // Per-pass rule: the plan of the NEXT batch's deposit (k_deposit_plan and its two item kernels) made ahead, on a
-    // stream of its own, while the deposit of this batch runs (plan_ahead); two item lists and queues for that.
-    struct Planned { int valid, buf, view, set, n_tiles; int32_t pass; int64_t first, count; unsigned long long view_gen, buf_gen; TileParams tp; } planned;
-    hipEvent_t ev_planned, ev_plan_inline, ev_set_free[2]; int plan_pending, inline_recorded, plan_ahead_on, set_used[2];
-    uint32_t* d_items_set[2]; unsigned int* d_item_q_set[2]; int item_set;
-    unsigned long long view_gen[NV], buf_gen[NBUF];
-    struct PreEye { int32_t pass; int view; };
-    std::deque<PreEye> pre_eyes;  // eye passes computed ahead of their calls, oldest first
-    int eye_ahead;                // how many of them at most (1, or 2: see `view`)
+    int32_t* d_order_r[3]; unsigned long long* d_hp_bb_r[3]; hipEvent_t ev_order[3];
+    int chain_n, view_chain[2];
+    hipStream_t eye_stream; hipEvent_t ev_eye_done, ev_eye_go;
+    struct { int valid, pass; } pre_eye;  // an eye pass computed ahead of its call
     int last_eye_pass;
     unsigned long long *d_rows_n, *h_rows_n; hipEvent_t ev_rows; int rows_pending; int64_t rows_cap;  // sppm_look_ahead_rows
     // Record exchange by destination (sppm_look_ahead_rows_to): with spatial ownership every rank knows every rank's
     // hitpoints (the eye pass is replicated), so it keeps, per view, the occupancy map of EVERY rank and sends a record
     // only to the ranks whose map holds its cell.  d_all_pix: the first eye pass's whole Morton order (rank r owns
     // positions [r P/N, (r+1) P/N)).
-    int all_maps; int32_t* d_all_pix; uint8_t* d_near_all_v[NV]; unsigned long long* d_bb_all_v[NV]; int view_pass[NV]; hipEvent_t ev_view[NV];
+    int all_maps; int32_t* d_all_pix; uint8_t* d_near_all_v[2]; unsigned long long* d_bb_all_v[2]; int view_pass[2]; hipEvent_t ev_view[2];
     unsigned long long *d_rows_n_to, *h_rows_n_to;  // [tile_stride]
     RecArrays rec_u, rec_s;  // unsorted (traced / received), sorted by bucket
     unsigned long long* d_rec_count;
@@ -428,9 +416,8 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
     c->ns = n_spheres;
     for (int b = 0; b < NTS; b++) c->tstream[b] = nullptr;
     for (int b = 0; b < NBUF; b++) { c->ev_traced[b] = nullptr; c->ev_free[b] = nullptr; }
-    c->eye_stream = nullptr; c->ev_eye_go = nullptr; c->ev_planned = c->ev_plan_inline = nullptr; c->ev_set_free[0] = c->ev_set_free[1] = nullptr; c->set_used[0] = c->set_used[1] = 0; c->plan_pending = 0; c->inline_recorded = 0; c->planned.valid = 0; c->item_set = 0;
-    c->d_items_set[0] = c->d_items_set[1] = nullptr; c->d_item_q_set[0] = c->d_item_q_set[1] = nullptr; for (int v = 0; v < NV; v++) c->view_gen[v] = 0; for (int b = 0; b < NBUF; b++) c->buf_gen[b] = 0; for (int k = 0; k < NORD; k++) { c->d_order_r[k] = nullptr; c->d_hp_bb_r[k] = nullptr; c->ev_order[k] = nullptr; }
-    c->chain_n = 0; for (int v = 0; v < NV; v++) c->view_chain[v] = -1;
+    c->eye_stream = nullptr; c->ev_eye_done = c->ev_eye_go = nullptr; for (int k = 0; k < 3; k++) { c->d_order_r[k] = nullptr; c->d_hp_bb_r[k] = nullptr; c->ev_order[k] = nullptr; }
+    c->chain_n = 0; c->view_chain[0] = c->view_chain[1] = -1;
     c->tap_cap = 0; c->d_tap_key = nullptr; c->d_tap_pix = nullptr; c->d_tap_n = nullptr;
     c->sampler = cfg->sampler; c->eye_eng.seed(cfg->seed_eye); c->lens_eng.seed(cfg->seed_lens); c->d_u_lens = nullptr; c->u_lens_cap = 0;
     c->d_u_eye = c->d_u_ph = nullptr; c->u_eye_cap = c->u_ph_cap = 0; c->u_eye_len = 0; c->d_eye_cnt = nullptr; c->d_ph_start = c->d_ph_consumed = nullptr;
@@ -490,21 +477,15 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
     if (cfg->update_rule == 1) {
         TRY(dev_alloc(c, &c->hp.tau, 3 * P)); TRY(dev_alloc(c, &c->hp.nd, P)); TRY(dev_alloc(c, &c->hp.dep, 4 * P));
     } else { c->hp.tau = c->hp.nd = nullptr; c->hp.dep = nullptr; }
-    c->cur_view = 0; c->pre_eyes.clear(); c->last_eye_pass = -1;
-    c->view[0] = c->hp;
-    for (int v = 1; v < NV; v++) {
-        c->view[v] = c->hp;
-        TRY(dev_alloc(c, &c->view[v].pos, 3 * P)); TRY(dev_alloc(c, &c->view[v].nrm, 3 * P)); TRY(dev_alloc(c, &c->view[v].w, 3 * P));
-        TRY(dev_alloc(c, &c->view[v].ld, 3 * P)); TRY(dev_alloc(c, &c->view[v].dist, P)); TRY(dev_alloc(c, &c->view[v].obj, P)); TRY(dev_alloc(c, &c->view[v].valid, P));
-    }
+    c->view[0] = c->hp; c->view[1] = c->hp; c->cur_view = 0; c->pre_eye.valid = 0; c->last_eye_pass = -1;
+    TRY(dev_alloc(c, &c->view[1].pos, 3 * P)); TRY(dev_alloc(c, &c->view[1].nrm, 3 * P)); TRY(dev_alloc(c, &c->view[1].w, 3 * P));
+    TRY(dev_alloc(c, &c->view[1].ld, 3 * P)); TRY(dev_alloc(c, &c->view[1].dist, P)); TRY(dev_alloc(c, &c->view[1].obj, P)); TRY(dev_alloc(c, &c->view[1].valid, P));
     // (stream priorities for the look-ahead streams were tried: the run hung until its time limit; not used)
     if (hipStreamCreateWithFlags(&c->eye_stream, hipStreamNonBlocking) != hipSuccess) { sppm_destroy(c); return fail(SPPM_ERR_HIP, "creating the eye stream failed"); }
-    if (hipEventCreateWithFlags(&c->ev_eye_go, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_planned, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_plan_inline, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_set_free[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_set_free[1], hipEventDisableTiming) != hipSuccess) {
+    if (hipEventCreateWithFlags(&c->ev_eye_done, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_eye_go, hipEventDisableTiming) != hipSuccess) {
         sppm_destroy(c); return fail(SPPM_ERR_HIP, "creating events failed");
     }
-    for (int k = 0; k < NORD; k++)
+    for (int k = 0; k < 3; k++)
         if (hipEventCreateWithFlags(&c->ev_order[k], hipEventDisableTiming) != hipSuccess) { sppm_destroy(c); return fail(SPPM_ERR_HIP, "creating events failed"); }
     // record buffers: one batch of photons, ~2.6 records per photon on the Cornell scene; 8x head room
     c->batch_min = std::max<int64_t>(64, env_i64("SPPM_BATCH_MIN", 32768));
@@ -523,8 +504,6 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
     c->pre.valid = 0;
     c->ahead_depth = (int)std::max<int64_t>(1, std::min<int64_t>(NBUF - 1, env_i64("SPPM_AHEAD", NBUF - 1)));
     c->prefetch = (int)env_i64("SPPM_PREFETCH", 1);
-    c->plan_ahead_on = (int)env_i64("SPPM_PLAN_AHEAD", 1);
-    c->eye_ahead = (c->plan_ahead_on && cfg->update_rule == 1 && cfg->tile_stride <= 1 && cfg->algorithm == 0) ? (int)std::max<int64_t>(1, std::min<int64_t>(NV - 1, env_i64("SPPM_EYE_AHEAD", 2))) : 1;
     if (c->sampler == 1) {
         c->prefetch = 0;  // a pass's photon stream offsets exist only once its photon pass has begun
     }
@@ -575,22 +554,21 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
         }
         c->n_own_pix = (int)own.size();
         c->n_owned = (c->n_own_pix + 63) / 64;  // virtual tiles of 64 hitpoints
-        TRY(dev_alloc(c, &c->d_own_pix, own.size(), false)); for (int k = 0; k < NORD; k++) TRY(dev_alloc(c, &c->d_order_r[k], own.size(), false));
+        TRY(dev_alloc(c, &c->d_own_pix, own.size(), false)); for (int k = 0; k < 3; k++) TRY(dev_alloc(c, &c->d_order_r[k], own.size(), false));
         c->d_order = c->d_order_r[0];
         TRY(dev_alloc(c, &c->d_hp_keys, own.size(), false)); TRY(dev_alloc(c, &c->d_hp_keys_out, own.size(), false));
-        for (int k = 0; k < NORD; k++) TRY(dev_alloc(c, &c->d_hp_bb_r[k], 6));
+        for (int k = 0; k < 3; k++) TRY(dev_alloc(c, &c->d_hp_bb_r[k], 6));
         c->d_hp_bb = c->d_hp_bb_r[0];
-        for (int v = 0; v < NV; v++) TRY(dev_alloc(c, &c->d_near_v[v], (size_t)NEAR_DIM * NEAR_DIM * NEAR_DIM));
-        c->d_near = c->d_near_v[0];
+        TRY(dev_alloc(c, &c->d_near_v[0], (size_t)NEAR_DIM * NEAR_DIM * NEAR_DIM)); TRY(dev_alloc(c, &c->d_near_v[1], (size_t)NEAR_DIM * NEAR_DIM * NEAR_DIM)); c->d_near = c->d_near_v[0];
         TRY(dev_alloc(c, &c->d_own_mask, P, false));  // every byte is written by the upload below
         c->all_maps = c->own_pending && c->gather_mode;
-        for (int v = 0; v < NV; v++) c->view_pass[v] = -1;
-        for (int v = 0; v < NV; v++)
+        c->view_pass[0] = c->view_pass[1] = -1;
+        for (int v = 0; v < 2; v++)
             if (hipEventCreateWithFlags(&c->ev_view[v], hipEventDisableTiming) != hipSuccess) { sppm_destroy(c); return fail(SPPM_ERR_HIP, "creating events failed"); }
         if (c->all_maps) {
             const size_t N = (size_t)c->tile_stride;
             TRY(dev_alloc(c, &c->d_all_pix, P, false));
-            for (int v = 0; v < NV; v++) { TRY(dev_alloc(c, &c->d_near_all_v[v], N * NEAR_DIM * NEAR_DIM * NEAR_DIM)); TRY(dev_alloc(c, &c->d_bb_all_v[v], N * 6)); }
+            for (int v = 0; v < 2; v++) { TRY(dev_alloc(c, &c->d_near_all_v[v], N * NEAR_DIM * NEAR_DIM * NEAR_DIM)); TRY(dev_alloc(c, &c->d_bb_all_v[v], N * 6)); }
             TRY(dev_alloc(c, &c->d_rows_n_to, N));
             if (hipHostMalloc((void**)&c->h_rows_n_to, N * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) { sppm_destroy(c); return fail(SPPM_ERR_HIP, "pinned memory for the row counts"); }
         }
@@ -604,10 +582,7 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
         if (hipStreamSynchronize(c->stream) != hipSuccess) { sppm_destroy(c); return fail(SPPM_ERR_HIP, "sppm_create: stream sync failed"); }
         c->sort_tmp_bytes = 0; c->d_sort_tmp = nullptr; c->order_valid = 0;
         TRY(dev_alloc(c, &c->d_est, (size_t)c->n_owned + 1)); TRY(dev_alloc(c, &c->d_items, (size_t)c->n_owned * 64 + 64, false)); TRY(dev_alloc(c, &c->d_items_raw, (size_t)c->n_owned * 64 + 64, false));
-        TRY(dev_alloc(c, &c->d_item_q, 2 + 2 * ITEM_CLASSES));
-        c->d_items_set[0] = c->d_items; c->d_item_q_set[0] = c->d_item_q;
-        if (cfg->update_rule == 1) { TRY(dev_alloc(c, &c->d_items_set[1], (size_t)c->n_owned * 64 + 64, false)); TRY(dev_alloc(c, &c->d_item_q_set[1], 2 + 2 * ITEM_CLASSES)); }
-        TRY(dev_alloc(c, &c->d_n_pieces, (size_t)c->n_owned + 1)); TRY(dev_alloc(c, &c->d_est_sum, 1)); TRY(dev_alloc(c, &c->d_ext_bin, (size_t)c->n_owned + 1)); c->est_valid = 0;
+        TRY(dev_alloc(c, &c->d_item_q, 2 + 2 * ITEM_CLASSES)); TRY(dev_alloc(c, &c->d_n_pieces, (size_t)c->n_owned + 1)); TRY(dev_alloc(c, &c->d_est_sum, 1)); TRY(dev_alloc(c, &c->d_ext_bin, (size_t)c->n_owned + 1)); c->est_valid = 0;
         c->split_factor = 4.0; c->est_per_photon = 0.0; c->est_range = 0;
         { const char* e = getenv("SPPM_SPLIT_FACTOR"); if (e && *e) c->split_factor = atof(e); }
         if (c->n_own_pix > 0) {
@@ -636,11 +611,9 @@ extern "C" int sppm_destroy(sppm_ctx* c)
     if (!c) return SPPM_OK;
     for (int b = 0; b < NTS; b++) if (c->tstream[b]) hipStreamSynchronize(c->tstream[b]);
     if (c->eye_stream) { hipStreamSynchronize(c->eye_stream); hipStreamDestroy(c->eye_stream); }
-    for (int k = 0; k < NORD; k++) if (c->ev_order[k]) hipEventDestroy(c->ev_order[k]);
+    for (int k = 0; k < 3; k++) if (c->ev_order[k]) hipEventDestroy(c->ev_order[k]);
+    if (c->ev_eye_done) hipEventDestroy(c->ev_eye_done);
     if (c->ev_eye_go) hipEventDestroy(c->ev_eye_go);
-    if (c->ev_planned) hipEventDestroy(c->ev_planned);
-    if (c->ev_plan_inline) hipEventDestroy(c->ev_plan_inline);
-    for (int k = 0; k < 2; k++) if (c->ev_set_free[k]) hipEventDestroy(c->ev_set_free[k]);
     hipStreamSynchronize(c->stream);
     for (int b = 0; b < NBUF; b++) { if (c->ev_traced[b]) hipEventDestroy(c->ev_traced[b]); if (c->ev_free[b]) hipEventDestroy(c->ev_free[b]); }
     for (int b = 0; b < NTS; b++) if (c->tstream[b]) hipStreamDestroy(c->tstream[b]);
@@ -650,7 +623,7 @@ extern "C" int sppm_destroy(sppm_ctx* c)
     if (c->h_stat) hipHostFree(c->h_stat);
     if (c->h_rows_n) hipHostFree(c->h_rows_n);
     if (c->h_rows_n_to) hipHostFree(c->h_rows_n_to);
-    for (int v = 0; v < NV; v++) if (c->ev_view[v]) hipEventDestroy(c->ev_view[v]);
+    for (int v = 0; v < 2; v++) if (c->ev_view[v]) hipEventDestroy(c->ev_view[v]);
     if (c->ev_rows) hipEventDestroy(c->ev_rows);
     for (int b = 0; b < 2; b++) if (c->ev_stat[b]) hipEventDestroy(c->ev_stat[b]);
     if (c->d_kd) hipFree(c->d_kd);
@@ -832,7 +805,7 @@ static int eye_pass_stream(sppm_ctx* c, EyeParams& ep)
         if (attempt >= 6) return fail(SPPM_ERR_OVERFLOW, "sppm_eye_pass: the eye paths consume more of the stream than 512 draws per path");
         need *= 2;
     }
-    hipLaunchKernelGGL(k_eye_pass_stream, dim3(nblk(c->P, 256)), dim3(256), scene_lds(c), st, scene_of(c), ep, c->hp, c->view[(c->cur_view + 1) % NV], c->d_counters, c->d_err);
+    hipLaunchKernelGGL(k_eye_pass_stream, dim3(nblk(c->P, 256)), dim3(256), scene_lds(c), st, scene_of(c), ep, c->hp, c->view[1 - c->cur_view], c->d_counters, c->d_err);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));  // the upload source shrinks below
     c->eye_pending.erase(c->eye_pending.begin(), c->eye_pending.begin() + (ptrdiff_t)total);
@@ -882,13 +855,11 @@ static int prepare_photon_stream(sppm_ctx* c, int32_t pass, int64_t count)
     return 0;
 }
 
-// One eye pass on stream st: reads view `iv` (the pass before: the direct term accumulates, a pixel keeps its
-// hitpoint where it finds no new one), writes the next one (hitpoints, valid flags, direct term, bounding box, tile
-// order).  The caller makes that view the current one once the work is ordered before its readers.
-static int eye_launch(sppm_ctx* c, int32_t pass, hipStream_t st, int iv)
+// One eye pass on stream st: reads the current view, writes the other one (hitpoints, valid flags, direct
+// term, bounding box, tile order).  The caller flips the views once the work is ordered before its readers.
+static int eye_launch(sppm_ctx* c, int32_t pass, hipStream_t st)
 {
-    const int nv = (iv + 1) % NV;
-    const HpArrays& in = c->view[iv];
+    const int nv = 1 - c->cur_view;
     EyeParams ep;
     ep.cam = c->cam; ep.W = c->cfg.width; ep.H = c->cfg.height; ep.samples = c->cfg.samples; ep.supersamples = c->cfg.supersamples;
     ep.pass = pass; ep.seed_eye = c->cfg.seed_eye; ep.initial_r2 = c->cfg.initial_radius2; ep.double_nee = c->cfg.double_nee;
@@ -905,15 +876,15 @@ static int eye_launch(sppm_ctx* c, int32_t pass, hipStream_t st, int iv)
     } else {
         if (c->dscene.n_cells) {  // large scenes: persistent wavefronts, lanes refilled (three waves per SIMD on every CU)
             HIPCHK(hipMemsetAsync(c->d_eye_next, 0, sizeof(unsigned long long), st));
-            hipLaunchKernelGGL(k_eye_pass_refill<1>, dim3(std::min(nblk(c->P, 256), 256 * 3)), dim3(256), scene_lds(c), st, scene_of(c), ep, in, c->view[nv], c->d_eye_next, c->d_counters);
+            hipLaunchKernelGGL(k_eye_pass_refill<1>, dim3(std::min(nblk(c->P, 256), 256 * 3)), dim3(256), scene_lds(c), st, scene_of(c), ep, c->hp, c->view[nv], c->d_eye_next, c->d_counters);
         }
-        else hipLaunchKernelGGL(k_eye_pass<0>, dim3(nblk(c->P, 256)), dim3(256), scene_lds(c), st, scene_of(c), ep, in, c->view[nv], c->d_counters);
+        else hipLaunchKernelGGL(k_eye_pass<0>, dim3(nblk(c->P, 256)), dim3(256), scene_lds(c), st, scene_of(c), ep, c->hp, c->view[nv], c->d_counters);
         HIPCHK(hipGetLastError());
     }
     if (c->gather_mode && c->n_own_pix > 0) {
         // re-form the gather tiles: sort this rank's hitpoints along a Morton curve of their positions, into the next
         // of the three order buffers
-        const int slot = c->chain_n % NORD;
+        const int slot = c->chain_n % 3;
         c->chain_n++;
         c->view_chain[nv] = slot;
         // bounding box seed: min slots all ones, max slots zero (ordered-int doubles); two memsets, nothing host-sourced
@@ -968,7 +939,7 @@ static int eye_launch(sppm_ctx* c, int32_t pass, hipStream_t st, int iv)
         }
         HIPCHK(hipEventRecord(c->ev_order[slot], st));
     }
-    c->view_pass[nv] = pass; c->view_gen[nv]++;
+    c->view_pass[nv] = pass;
     HIPCHK(hipEventRecord(c->ev_view[nv], st));
     return 0;
 }
@@ -977,7 +948,7 @@ static int eye_launch(sppm_ctx* c, int32_t pass, hipStream_t st, int iv)
 // the tile order made with it
 static int flip_view(sppm_ctx* c)
 {
-    c->cur_view = (c->cur_view + 1) % NV;
+    c->cur_view ^= 1;
     c->hp = c->view[c->cur_view]; c->d_near = c->d_near_v[c->cur_view];
     const int own = c->view_chain[c->cur_view];
     if (own >= 0) {
@@ -988,45 +959,38 @@ static int flip_view(sppm_ctx* c)
     return 0;
 }
 
-// Eye pass of a pass after the current one ahead of its call, on the eye stream, while the gather of the current
-// pass runs: eye paths do not depend on photons.  Assumes the caller goes on with sppm_eye_pass(last + 1), (last + 2);
-// anything else drops them.  Passes are made ahead in order; at most c->eye_ahead at a time.
+// Eye pass of pass+1 ahead of its call, on the eye stream, while the gather of `pass` runs: eye paths do not
+// depend on photons.  Assumes the caller goes on with sppm_eye_pass(pass + 1); anything else drops it.
 static int eye_prefetch(sppm_ctx* c, int32_t pass)
 {
-    if (!c->prefetch || c->sampler == 1 || c->algo == 1 || (int)c->pre_eyes.size() >= c->eye_ahead) return 0;
-    const int32_t newest = c->pre_eyes.empty() ? c->last_eye_pass : c->pre_eyes.back().pass;
-    if (pass != newest + 1) return 0;
-    const int iv = c->pre_eyes.empty() ? c->cur_view : c->pre_eyes.back().view;
-    // the view it writes was last read by the pass NV - 1 before it, whose work is all on the context's stream by the
-    // time ev_eye_go was recorded (eye_go)
+    if (!c->prefetch || c->sampler == 1 || c->pre_eye.valid || c->algo == 1) return 0;
+    // the other view was last read by the pass before this one, whose work is all on the context's stream by now
+    HIPCHK(hipEventRecord(c->ev_eye_go, c->stream));
     HIPCHK(hipStreamWaitEvent(c->eye_stream, c->ev_eye_go, 0));
-    int rc = eye_launch(c, pass, c->eye_stream, iv);
+    int rc = eye_launch(c, pass, c->eye_stream);
     if (rc) return rc;
-    c->pre_eyes.push_back({pass, (iv + 1) % NV});
+    HIPCHK(hipEventRecord(c->ev_eye_done, c->eye_stream));
+    c->pre_eye.valid = 1; c->pre_eye.pass = pass;
     return 0;
 }
-// marks the point on the context's stream behind which eye passes made ahead may start
-static int eye_go(sppm_ctx* c) { HIPCHK(hipEventRecord(c->ev_eye_go, c->stream)); return 0; }
 
 extern "C" int sppm_eye_pass(sppm_ctx* c, int32_t pass)
 {
     if (!c || pass < 0) return fail(SPPM_ERR_INVALID, "sppm_eye_pass: bad argument");
     CTX_DEVICE(c, "sppm_eye_pass");
     if (c->algo == 1 && pass != 0) return fail(SPPM_ERR_INVALID, "sppm_eye_pass: classic progressive photon mapping traces its hitpoints once (pass 0)");
-    if (!c->pre_eyes.empty()) {
-        if (c->pre_eyes.front().pass == pass && c->pre_eyes.front().view == (c->cur_view + 1) % NV) {  // computed ahead: order it before what follows on the context's stream
-            HIPCHK(hipStreamWaitEvent(c->stream, c->ev_view[c->pre_eyes.front().view], 0));
-            c->pre_eyes.pop_front();
+    if (c->pre_eye.valid) {
+        c->pre_eye.valid = 0;
+        if (c->pre_eye.pass == pass) {  // computed ahead: order it before what follows on the context's stream
+            HIPCHK(hipStreamWaitEvent(c->stream, c->ev_eye_done, 0));
             int rcf = flip_view(c);
             if (rcf) return rcf;
             c->last_eye_pass = pass;
             return SPPM_OK;
         }
-        HIPCHK(hipStreamSynchronize(c->eye_stream));  // not the pass that was expected: their work is dropped
-        c->pre_eyes.clear();
-        c->planned.valid = 0;
+        HIPCHK(hipStreamSynchronize(c->eye_stream));  // not the pass that was expected: its work is dropped
     }
-    int rc = eye_launch(c, pass, c->stream, c->cur_view);
+    int rc = eye_launch(c, pass, c->stream);
     if (rc) return rc;
     rc = flip_view(c);
     if (rc) return rc;
@@ -1046,7 +1010,6 @@ static void set_cur(sppm_ctx* c, int b)
 static int trace_into(sppm_ctx* c, int b, int32_t pass, int64_t first, int64_t count, hipStream_t st)
 {
     TraceParams tp;
-    c->buf_gen[b]++;
     tp.pass = pass; tp.first = first; tp.count = count;
     tp.photons_per_pass = c->cfg.photons_per_pass; tp.seed_photon = c->cfg.seed_photon; tp.flux_scale = c->flux_scale; tp.rec_cap = c->rec_buf[b].cap;
     // persistent wavefronts that take photons from one counter, never more than the photons need
@@ -1102,7 +1065,6 @@ extern "C" int sppm_trace(sppm_ctx* c, int32_t pass, int64_t first, int64_t coun
 
 static int discard_prefetch(sppm_ctx* c);
 static int eye_prefetch(sppm_ctx* c, int32_t pass);
-static int eye_go(sppm_ctx* c);
 
 extern "C" int sppm_look_ahead(sppm_ctx* c, int32_t pass, int64_t first, int64_t count)
 {
@@ -1122,7 +1084,7 @@ extern "C" int sppm_look_ahead(sppm_ctx* c, int32_t pass, int64_t first, int64_t
     if (rc) return rc;
     HIPCHK(hipEventRecord(c->ev_traced[nb], TSTREAM(c, nb)));
     c->pre.valid = 1; c->pre.buf = nb; c->pre.pass = pass; c->pre.first = first; c->pre.count = count;
-    if (pass == c->last_eye_pass + 1 && c->pre_eyes.empty()) { rc = eye_go(c); if (rc) return rc; rc = eye_prefetch(c, pass); if (rc) return rc; }
+    if (pass == c->last_eye_pass + 1) { rc = eye_prefetch(c, pass); if (rc) return rc; }
     return SPPM_OK;
 }
 
@@ -1182,7 +1144,7 @@ extern "C" int sppm_look_ahead_rows_to(sppm_ctx* c, int32_t pass, int64_t first,
     int v = -1;
     if (!c->own_pending) {
         if (c->last_eye_pass == pass && c->view_pass[c->cur_view] == pass) v = c->cur_view;
-        else for (const sppm_ctx::PreEye& q : c->pre_eyes) if (q.pass == pass && c->view_pass[q.view] == pass) v = q.view;
+        else if (c->pre_eye.valid && c->pre_eye.pass == pass && c->view_pass[1 - c->cur_view] == pass) v = 1 - c->cur_view;
     }
     if (v >= 0) HIPCHK(hipStreamWaitEvent(ts, c->ev_view[v], 0));
     HIPCHK(hipMemsetAsync(c->d_rows_n_to, 0, (size_t)N * sizeof(unsigned long long), ts));
@@ -1569,62 +1531,6 @@ static int gather_tiles(sppm_ctx* c)
     return SPPM_OK;
 }
 
-// what the plan and the deposit kernel both take: the tiles (order), the batch's grid, the cluster distance
-static TileParams deposit_params(const sppm_ctx* c, const TileGrid& g, const int32_t* order)
-{
-    TileParams tp;
-    memset(&tp, 0, sizeof tp);
-    tp.gather_r2 = c->cfg.gather_radius2; tp.alpha = c->cfg.alpha; tp.rule = 1;
-    tp.order = order; tp.n_pix = c->n_own_pix; tp.n_owned = c->n_owned;
-    tp.g = g;
-    tp.cluster_d = c->gs.cluster_d;
-    return tp;
-}
-// k_deposit_plan + k_items_count + k_items_place on stream st into item set `set`; the statistics snapshot goes to the
-// next pinned slot, its event is recorded on st
-static int launch_deposit_plan(sppm_ctx* c, hipStream_t st, const HpArrays& hp, const sppm_ctx::BinSet& BS, const TileParams& tp, int n_dep_tiles, int set,
-                               const unsigned long long* d_bb, unsigned long long* d_rec_count)
-{
-    hipLaunchKernelGGL(k_deposit_plan, dim3(nblk(n_dep_tiles, 4)), dim3(256), 0, st, hp, BS.cell_start, tp, n_dep_tiles, (uint32_t)c->dep_chunk, c->d_items_raw, c->d_n_pieces, c->d_est, c->d_item_q_set[set],
-                       c->d_ext_bin, c->d_stats);
-    hipLaunchKernelGGL(k_items_count, dim3(nblk(n_dep_tiles, 256)), dim3(256), 0, st, c->d_items_raw, c->d_n_pieces, n_dep_tiles, c->d_item_q_set[set], c->d_ext_bin, c->d_stats);
-    hipLaunchKernelGGL(k_items_place, dim3(nblk(n_dep_tiles, 256)), dim3(256), 0, st, c->d_items_raw, c->d_n_pieces, n_dep_tiles, c->d_item_q_set[set], c->d_items_set[set], d_rec_count,
-                       c->d_stats, d_bb, c->d_counters, c->d_stat_map + c->stat_w);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(c->ev_stat[c->stat_w], st));
-    c->stat_w ^= 1; c->stat_n++;
-    return 0;
-}
-
-// Per-pass rule: plan the deposit of the batch that is expected next -- ring buffer `buf`, binned ahead on its tracer
-// stream, against the hitpoints of `view` -- on the eye stream (behind the eye pass that makes that view, ahead of the
-// next one), while the deposit just enqueued runs.  The plan needs the hitpoints' positions and the batch's cell table;
-// radii enter only its COST ESTIMATES (how many chunks a region is cut into, which items start first): the deposit kernel
-// forms the same clusters from the same positions and cuts whatever the region holds then into the planned number of
-// chunks, so planning with the radii of one pass earlier changes no result.  What is left between two deposit kernels is
-// the end of the pass (k_end_pass_resolve) alone.
-static int plan_ahead(sppm_ctx* c, int buf, int view, int32_t pass, int64_t first, int64_t count)
-{
-    const sppm_ctx::BinSet& BS = c->bins[buf];
-    const int slot = c->view_chain[view];
-    if (!BS.binned || slot < 0 || c->n_owned == 0 || c->tile_stride != 1 || c->plan_pending) return 0;
-    hipStream_t ps = c->eye_stream;
-    if (c->inline_recorded) HIPCHK(hipStreamWaitEvent(ps, c->ev_plan_inline, 0));  // the plan's scratch arrays are shared with a plan made in place
-    HIPCHK(hipStreamWaitEvent(ps, c->ev_order[slot], 0));
-    HIPCHK(hipStreamWaitEvent(ps, c->ev_traced[buf], 0));
-    sppm_ctx::Planned& pl = c->planned;
-    pl.tp = deposit_params(c, BS.g, c->d_order_r[slot]);
-    pl.n_tiles = (c->n_own_pix + DEP_TILE - 1) / DEP_TILE;
-    pl.set = c->item_set; c->item_set ^= 1;
-    if (c->set_used[pl.set]) HIPCHK(hipStreamWaitEvent(ps, c->ev_set_free[pl.set], 0));  // the deposit that last read this item list and queue
-    int rc = launch_deposit_plan(c, ps, c->view[view], BS, pl.tp, pl.n_tiles, pl.set, c->d_hp_bb_r[slot], c->d_rec_count_buf[buf]);
-    if (rc) return rc;
-    HIPCHK(hipEventRecord(c->ev_planned, ps));
-    pl.valid = 1; pl.buf = buf; pl.view = view; pl.pass = pass; pl.first = first; pl.count = count; pl.view_gen = c->view_gen[view]; pl.buf_gen = c->buf_gen[buf];
-    c->plan_pending = 1;
-    return 0;
-}
-
 // The per-pass rule's gather of the current record buffer (sppm_deposit.hpp): bin by cell (one slab), plan the work
 // items from the summed-area table, deposit.  Same stream discipline as gather_tiles.
 static int deposit_tiles(sppm_ctx* c)
@@ -1641,33 +1547,28 @@ static int deposit_tiles(sppm_ctx* c)
     if (!c->order_valid) return fail(SPPM_ERR_STATE, "sppm_gather: no eye pass has run on this context yet");
     int rc = stats_read(c);
     if (rc) return rc;
-    // (the statistics for the batch after this one are made by the plan and its two item kernels: no launches of their own)
+    // (the statistics for the batch after this one are made by the plan and its two item kernels below: no launches of their own)
     if (!BS.binned) { rc = bin_into(c, c->cur, grid_for(c, c->rec_first, range), st, c->tile_stride > 1); if (rc) return rc; }
     const TileGrid g = BS.g;
     TileParams tp;
-    const int n_dep_tiles = (c->n_own_pix + DEP_TILE - 1) / DEP_TILE;  // DEP_H hitpoints per lane
-    int set;
-    const sppm_ctx::Planned& pl = c->planned;
-    if (c->plan_pending) { HIPCHK(hipStreamWaitEvent(st, c->ev_planned, 0)); c->plan_pending = 0; }  // (whether its plan is used or not)
-    if (pl.valid && pl.buf == c->cur && pl.buf_gen == c->buf_gen[c->cur] && pl.view == c->cur_view && pl.view_gen == c->view_gen[c->cur_view] && pl.first == c->rec_first &&
-        pl.count == range && pl.tp.order == c->d_order && pl.n_tiles == n_dep_tiles && c->veto_dev.n == nullptr) {
-        // planned ahead, while the deposit before this one ran (plan_ahead): the items are there
-        tp = pl.tp;
-        set = pl.set;
-    } else {
-        tp = deposit_params(c, g, c->d_order);
-        set = c->item_set; c->item_set ^= 1;
-        rc = launch_deposit_plan(c, st, c->hp, BS, tp, n_dep_tiles, set, c->d_hp_bb, c->d_rec_count);
-        if (rc) return rc;
-        HIPCHK(hipEventRecord(c->ev_plan_inline, st)); c->inline_recorded = 1;
-    }
-    c->planned.valid = 0;
+    memset(&tp, 0, sizeof tp);
+    tp.gather_r2 = c->cfg.gather_radius2; tp.alpha = c->cfg.alpha; tp.rule = 1;
+    tp.order = c->d_order; tp.n_pix = c->n_own_pix; tp.n_owned = c->n_owned;
     tp.tap_key = c->d_tap_key; tp.tap_pix = c->d_tap_pix; tp.tap_n = c->d_tap_n; tp.tap_cap = c->tap_cap;
+    tp.g = g;
+    tp.cluster_d = c->gs.cluster_d;
     tp.veto = c->veto_dev;
     c->gather_j++;
+    const int n_dep_tiles = (c->n_own_pix + DEP_TILE - 1) / DEP_TILE;  // DEP_H hitpoints per lane
+    hipLaunchKernelGGL(k_deposit_plan, dim3(nblk(n_dep_tiles, 4)), dim3(256), 0, st, c->hp, BS.cell_start, tp, n_dep_tiles, (uint32_t)c->dep_chunk, c->d_items_raw, c->d_n_pieces, c->d_est, c->d_item_q,
+                       c->d_ext_bin, c->d_stats);
+    hipLaunchKernelGGL(k_items_count, dim3(nblk(n_dep_tiles, 256)), dim3(256), 0, st, c->d_items_raw, c->d_n_pieces, n_dep_tiles, c->d_item_q, c->d_ext_bin, c->d_stats);
+    hipLaunchKernelGGL(k_items_place, dim3(nblk(n_dep_tiles, 256)), dim3(256), 0, st, c->d_items_raw, c->d_n_pieces, n_dep_tiles, c->d_item_q, c->d_items, c->d_rec_count,
+                       c->d_stats, c->d_hp_bb, c->d_counters, c->d_stat_map + c->stat_w);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(c->ev_stat[c->stat_w], st));
+    c->stat_w ^= 1; c->stat_n++;
     c->est_valid = 0;  // (the estimates of the ordered gather's plan are not made here)
-    uint32_t* const d_items = c->d_items_set[set];
-    unsigned int* const d_item_q = c->d_item_q_set[set];
     const int blocks = std::max(1, std::min(nblk(n_dep_tiles, 4) * 4, (int)env_i64("SPPM_DEP_BLOCKS", 256 * 3)));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->timing) { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventRecord(e0, st)); }
@@ -1677,7 +1578,7 @@ static int deposit_tiles(sppm_ctx* c)
     const bool dep_wg = env_i64("SPPM_DEP_WG", 0) != 0 && DEP_H == 1;
     if (stamps) {
         HIPCHK(hipMemsetAsync(c->d_counters + 15, 0, 9 * sizeof(unsigned long long), st));
-        hipLaunchKernelGGL((k_deposit_tiles<false, true>), dim3(blocks), dim3(256), 0, st, c->hp, BS.rec_s, BS.cell_start, tp, d_items, d_item_q, c->d_counters, c->d_err);
+        hipLaunchKernelGGL((k_deposit_tiles<false, true>), dim3(blocks), dim3(256), 0, st, c->hp, BS.rec_s, BS.cell_start, tp, c->d_items, c->d_item_q, c->d_counters, c->d_err);
         unsigned long long t[24];
         HIPCHK(hipMemcpyAsync(t, c->d_counters, sizeof t, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
@@ -1686,23 +1587,22 @@ static int deposit_tiles(sppm_ctx* c)
                 100.0 * t[16] / tot, 100.0 * t[17] / tot, 100.0 * t[18] / tot, 100.0 * t[19] / tot, 100.0 * t[23] / tot, 100.0 * t[20] / tot, 100.0 * t[21] / tot, g.nx, g.ny, g.nz);
         fprintf(stderr, "[sppm]   staged records by class: distance test only %llu, full test %llu (records rejected for the whole cluster are not staged)\n", t[22], t[15]);
     } else if (c->veto_dev.n != nullptr) {  // the K cap acts on this batch: the pairs it dropped are withheld
-        if (c->tap_cap > 0) hipLaunchKernelGGL((k_deposit_tiles<true, false, true>), dim3(blocks), dim3(256), 0, st, c->hp, BS.rec_s, BS.cell_start, tp, d_items, d_item_q, c->d_counters, c->d_err);
-        else hipLaunchKernelGGL((k_deposit_tiles<false, false, true>), dim3(blocks), dim3(256), 0, st, c->hp, BS.rec_s, BS.cell_start, tp, d_items, d_item_q, c->d_counters, c->d_err);
+        if (c->tap_cap > 0) hipLaunchKernelGGL((k_deposit_tiles<true, false, true>), dim3(blocks), dim3(256), 0, st, c->hp, BS.rec_s, BS.cell_start, tp, c->d_items, c->d_item_q, c->d_counters, c->d_err);
+        else hipLaunchKernelGGL((k_deposit_tiles<false, false, true>), dim3(blocks), dim3(256), 0, st, c->hp, BS.rec_s, BS.cell_start, tp, c->d_items, c->d_item_q, c->d_counters, c->d_err);
     } else if (dep_wg) {
-        if (c->tap_cap > 0) hipLaunchKernelGGL(k_deposit_wg<true>, dim3(blocks), dim3(256), 0, st, c->hp, BS.rec_s, BS.cell_start, tp, d_items, d_item_q, c->d_counters, c->d_err);
-        else hipLaunchKernelGGL(k_deposit_wg<false>, dim3(blocks), dim3(256), 0, st, c->hp, BS.rec_s, BS.cell_start, tp, d_items, d_item_q, c->d_counters, c->d_err);
+        if (c->tap_cap > 0) hipLaunchKernelGGL(k_deposit_wg<true>, dim3(blocks), dim3(256), 0, st, c->hp, BS.rec_s, BS.cell_start, tp, c->d_items, c->d_item_q, c->d_counters, c->d_err);
+        else hipLaunchKernelGGL(k_deposit_wg<false>, dim3(blocks), dim3(256), 0, st, c->hp, BS.rec_s, BS.cell_start, tp, c->d_items, c->d_item_q, c->d_counters, c->d_err);
     } else if (c->tap_cap > 0)
-        hipLaunchKernelGGL(k_deposit_tiles<true>, dim3(blocks), dim3(256), 0, st, c->hp, BS.rec_s, BS.cell_start, tp, d_items, d_item_q, c->d_counters, c->d_err);
+        hipLaunchKernelGGL(k_deposit_tiles<true>, dim3(blocks), dim3(256), 0, st, c->hp, BS.rec_s, BS.cell_start, tp, c->d_items, c->d_item_q, c->d_counters, c->d_err);
     else
-        hipLaunchKernelGGL(k_deposit_tiles<false>, dim3(blocks), dim3(256), 0, st, c->hp, BS.rec_s, BS.cell_start, tp, d_items, d_item_q, c->d_counters, c->d_err);
+        hipLaunchKernelGGL(k_deposit_tiles<false>, dim3(blocks), dim3(256), 0, st, c->hp, BS.rec_s, BS.cell_start, tp, c->d_items, c->d_item_q, c->d_counters, c->d_err);
     if (c->timing) { HIPCHK(hipEventRecord(e1, st)); c->ev.push_back({e0, e1}); }
     HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(c->ev_set_free[set], st)); c->set_used[set] = 1;
     BS.binned = 0;
     c->gather_batches++;
     c->photons_applied += (uint64_t)range;
     c->rec_first = c->rec_end = 0;
-    // (the buffer's record counter was cleared by k_items_place)
+    // (the buffer's record counter was cleared by k_items_bases)
     return SPPM_OK;
 }
 
@@ -1793,7 +1693,6 @@ static int cap_build_tree(sppm_ctx* c)
     if (getenv("SPPM_DEBUG")) fprintf(stderr, "[sppm] K cap: tree of %d hitpoints built on the host in %.1f ms\n", n, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_build).count());
     return 0;
 }
-static bool cap_enforced(const sppm_ctx* c) { return c->cfg.check_gather_max == 0 && c->cfg.gather_max < (int64_t)c->P && c->P > 0; }
 // the capped search of every record in the current buffer; leaves the dropped pairs in the Veto table
 static int cap_search(sppm_ctx* c)
 {
@@ -1899,7 +1798,7 @@ extern "C" int sppm_gather(sppm_ctx* c)
     c->veto_dev.n = nullptr;
     // check_gather_max 0 (default): the K cap is enforced, exactly, whenever it could act (K below the number of
     // hitpoints in the tree); 1: counted only (above); 2: ignored (the uncapped set, a documented deviation)
-    if (cap_enforced(c) && c->rec_end != c->rec_first) {
+    if (c->cfg.check_gather_max == 0 && c->cfg.gather_max < (int64_t)c->P && c->P > 0 && c->rec_end != c->rec_first) {
         int rc = cap_search(c);
         if (rc) return rc;
     }
@@ -1921,9 +1820,6 @@ static int discard_prefetch(sppm_ctx* c)
 {
     std::vector<sppm_ctx::Pre> all(c->ahead.begin(), c->ahead.end());
     if (c->pre.valid) all.push_back(c->pre);
-    // a plan made ahead was for one of these batches and clears its buffer's record counter: what follows (the counter's
-    // reset, the buffer's release to the tracer) is ordered behind it
-    if (c->plan_pending) { HIPCHK(hipStreamWaitEvent(c->stream, c->ev_planned, 0)); c->plan_pending = 0; }
     if (!all.empty() && getenv("SPPM_DEBUG")) fprintf(stderr, "[sppm] look-ahead dropped: %zu batches (first: pass %d photons %lld+%lld)\n", all.size(), all[0].pass, (long long)all[0].first, (long long)all[0].count);
     for (const sppm_ctx::Pre& q : all) {
         const int b = q.buf;
@@ -1935,7 +1831,6 @@ static int discard_prefetch(sppm_ctx* c)
     }
     c->ahead.clear();
     c->pre.valid = 0;
-    c->planned.valid = 0;
     return 0;
 }
 
@@ -2016,18 +1911,6 @@ extern "C" int sppm_photon_pass(sppm_ctx* c, int32_t pass, int64_t first, int64_
             rc = launch_ahead(c, cur.buf, cur.pass, cur.first, cur.count);
             if (rc) return rc;
         }
-        // The caller is expected to go on with the next passes: their eye passes run ahead too (eye paths do not depend on
-        // photons), behind this point of the context's stream (the end of the pass before this one).
-        // (An eye pass made ahead and the tracer start where the gather BEFORE this one ends and so run against the small
-        // kernels between two gather kernels.  Holding the tracer, or both, back until those kernels are done was
-        // measured in round 3: slower -- whatever starts beside a running gather kernel gets one workgroup slot per CU
-        // and lasts as long as the gather does.)
-        const bool last_batch = cur.first + cur.count >= first + count;
-        const bool eyes_ahead = c->algo == 0 && c->prefetch && depth > 0 && last_batch;
-        if (eyes_ahead) {
-            rc = eye_go(c); if (rc) return rc;
-            if (c->eye_ahead == 1) { rc = eye_prefetch(c, pass + 1); if (rc) return rc; }  // (two ahead: behind the plan, below)
-        }
         // top the queue up with the batches expected next (ring buffers cur.buf + 1, + 2, ...)
         {
             sppm_ctx::Pre last = cur;
@@ -2043,6 +1926,12 @@ extern "C" int sppm_photon_pass(sppm_ctx* c, int32_t pass, int64_t first, int64_
                 last = nb; applied += (uint64_t)nb.count;
             }
         }
+        // the caller is expected to go on with the next pass: its eye pass runs ahead too (eye paths do not depend on photons).
+        // (Both start where the gather BEFORE this one ends and so run against the small kernels between two gather
+        // kernels.  Holding the tracer, or both, back until those kernels are done was measured in round 3: the window
+        // shrinks to 70 us of kernels, but the next window then waits for the eye pass, which runs 3 ms in the gather's
+        // shadow instead of 0.4 ms -- 249 and 255 M photons/s against 267.)
+        if (c->algo == 0 && !c->ahead.empty() && c->ahead.front().pass == pass + 1) { rc = eye_prefetch(c, pass + 1); if (rc) return rc; }
         // gather the current batch
         HIPCHK(hipStreamWaitEvent(c->stream, c->ev_traced[cur.buf], 0));
         set_cur(c, cur.buf);
@@ -2050,17 +1939,6 @@ extern "C" int sppm_photon_pass(sppm_ctx* c, int32_t pass, int64_t first, int64_
         rc = sppm_gather(c);
         if (rc) return rc;
         HIPCHK(hipEventRecord(c->ev_free[cur.buf], c->stream));
-        // per-pass rule: the plan of the next batch's deposit, made while this deposit runs (plan_ahead)
-        if (c->plan_ahead_on && c->gather_mode && c->cfg.update_rule == 1 && !c->ahead.empty() && !cap_enforced(c)) {
-            const sppm_ctx::Pre& nb = c->ahead.front();
-            if (nb.pass == pass) { rc = plan_ahead(c, nb.buf, c->cur_view, nb.pass, nb.first, nb.count); if (rc) return rc; }
-            else if (nb.pass == pass + 1 && !c->pre_eyes.empty() && c->pre_eyes.front().pass == pass + 1) {
-                rc = plan_ahead(c, nb.buf, c->pre_eyes.front().view, nb.pass, nb.first, nb.count); if (rc) return rc;
-            }
-        }
-        // two eye passes ahead: the plan above sits on the eye stream between the eye pass it needs (made during the pass
-        // before this one) and the ones started now, which have until the gather after next
-        if (eyes_ahead && c->eye_ahead > 1) for (int k = 1; k <= c->eye_ahead; k++) { rc = eye_prefetch(c, pass + k); if (rc) return rc; }
         if (cur.first + cur.count >= first + count) break;
         sppm_ctx::Pre nx;
         const int64_t nf = cur.first + cur.count;
