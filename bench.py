@@ -23,7 +23,7 @@ At N = 1 the other rule is measured in the same run and reported beside the prim
 the relative RMSE between the two images; `k_cap` reports two passes with the reference's K = 10000 cap enforced
 exactly (the timed renders search uncapped: config.gather_max); `cpu_baseline` times the oracle's all-core photon pass
 on a bounded sample.  `roofline` is the gather kernel of the primary rule: algorithmic FP64 operations over HIP-event
-kernel time against the vector FP64 peak, with the committed rocprofv3 --pmc counters (profiles/r02_pmc_rule<R>.json).
+kernel time against the vector FP64 peak, with the committed rocprofv3 --pmc counters (profiles/r03_pmc_rule<R>.json).
 """
 import argparse
 import json
@@ -242,11 +242,11 @@ def measured_fma_peak(torch):
 
 def measured_counters(width, height, photons, rule, steps):
     """Per-launch hardware counters of the gather kernel from the committed rocprofv3 --pmc passes of this script
-    (profiles/r02_pmc_rule<R>.json, made by tools/pmc_passes.sh + tools/rocpd_summary.py sq: HBM bytes = 2 x FETCH_SIZE
+    (profiles/r03_pmc_rule<R>.json, made by tools/pmc_passes.sh + tools/rocpd_summary.py sq: HBM bytes = 2 x FETCH_SIZE
     (gfx950) + WRITE_SIZE, SQ busy / VALU / LDS cycles).  Counters cannot be read from inside a normal run; a file
     matches by (width, height, photons per pass, rule) -- it says which passes it was averaged over."""
     try:
-        with open(os.path.join(ROOT, "profiles", f"r02_pmc_rule{rule}.json")) as f:
+        with open(os.path.join(ROOT, "profiles", f"r03_pmc_rule{rule}.json")) as f:
             t = json.load(f)
     except (OSError, ValueError):
         return None
@@ -378,7 +378,7 @@ def report(args, world, rule, r, table_name):
             # the byte accounting of SURVEY 8(d), kept beside the bound that the counters show
             "alg_bytes_per_launch": alg_bytes / g_launch, "alg_GBps": alg_bytes / max(g_ns, 1),
             "update_bytes_GBps_at_60B": 60.0 * upd0 / max(g_ns, 1), "update_bytes_frac_of_hbm_peak": 60.0 * upd0 / max(g_ns, 1) / 8000.0,
-            "note": "rank 0; bound = the vector ALU: the committed SQ counters (profiles/r02_pmc_rule%d.json) show it as the busiest unit of the kernel (VALU busy %s "
+            "note": "rank 0; bound = the vector ALU: the committed SQ counters (profiles/r03_pmc_rule%d.json) show it as the busiest unit of the kernel (VALU busy %s "
                     "of the time every SIMD is occupied, LDS %s, HBM a few percent of 8 TB/s), so the roofline is the FP64 vector peak; the kernel does not "
                     "saturate the pipe -- three to four wavefronts of 128 registers per SIMD leave dependent instructions and LDS round trips exposed, and every second instruction issued is scalar or LDS work around the arithmetic.  achieved = 23 flop x "
                     "(record, hitpoint) pairs examined%s / kernel time from HIP events on the kernel's stream: ALGORITHMIC operations (the reference's test of a "

@@ -99,6 +99,7 @@ struct sppm_ctx {
     double fx_scale;          // per-pass rule: fixed point of the deposits (sppm_deposit.hpp), a power of two
     double cell_factor_dep;   // per-pass rule: cell size of the record grid as a share of the median tile extent
     int64_t dep_chunk;        // per-pass rule: records per work item
+    double dep_light, dep_heavy;  // per-pass rule: pairs per photon at which the deposit kernel runs on 576 / 768 workgroups (deposit_tiles)
     int order_valid;
     sppm_sphere* d_spheres; int ns;
     DevScene dscene;   // what the kernels get: the table, and for large scenes the grid over the small spheres
@@ -158,7 +159,7 @@ struct sppm_ctx {
     StatSlot* h_stat; StatSlot* d_stat_map;  // pinned host memory and the address the device writes it through
     hipEvent_t ev_stat[2]; int stat_w; long stat_n;
     struct { double lo[3], cell, cluster_d; int64_t dims[3], ncells; int valid; } gs;  // spatial part of the grid, from the last statistics read
-    unsigned long long snap_prev[24]; int snap_prev_valid; long gather_j; int64_t hist_S[4], hist_B[4];
+    unsigned long long snap_prev[24]; int snap_prev_valid; long gather_j; int64_t hist_S[4], hist_B[4], hist_range[4]; double pairs_per_photon;  // pairs_per_photon: what the deposit kernel examined two batches ago (0: not known)
     uint32_t n_buckets;
     int64_t batch_photons;
     // K cap of the reference's search (sppm_cap.hpp): the reference's hitpoint vector in the order its tree leaves it
@@ -411,6 +412,7 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
     c->cell_factor_dep = 0.15;
     { const char* e = getenv("SPPM_DEP_CELL_FACTOR"); if (e && *e && atof(e) > 0.0) c->cell_factor_dep = atof(e); }
     c->dep_chunk = std::max<int64_t>(64, env_i64("SPPM_DEP_CHUNK", 4096));
+    c->dep_light = (double)env_i64("SPPM_DEP_LIGHT", 1700); c->dep_heavy = std::max(c->dep_light + 1.0, (double)env_i64("SPPM_DEP_HEAVY", 2400));
     c->rec_first = c->rec_end = 0;
     c->photons_applied = 0;
     c->ns = n_spheres;
@@ -534,7 +536,7 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
     if (hipHostMalloc((void**)&c->h_rows_n, sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess || hipEventCreateWithFlags(&c->ev_rows, hipEventDisableTiming) != hipSuccess) {
         sppm_destroy(c); return fail(SPPM_ERR_HIP, "pinned memory / event for the packed rows");
     }
-    c->h_stat = nullptr; c->ev_stat[0] = c->ev_stat[1] = nullptr; c->stat_w = 0; c->stat_n = 0; c->gs.valid = 0; c->snap_prev_valid = 0; c->gather_j = 0;
+    c->h_stat = nullptr; c->ev_stat[0] = c->ev_stat[1] = nullptr; c->stat_w = 0; c->stat_n = 0; c->gs.valid = 0; c->snap_prev_valid = 0; c->gather_j = 0; c->pairs_per_photon = 0.0;
     c->d_stat_map = nullptr;
     if (hipHostMalloc((void**)&c->h_stat, 2 * sizeof(sppm_ctx::StatSlot), hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer((void**)&c->d_stat_map, c->h_stat, 0) != hipSuccess) { sppm_destroy(c); return fail(SPPM_ERR_HIP, "pinned host memory for the tile statistics"); }
@@ -1361,6 +1363,10 @@ static int stats_read(sppm_ctx* c)
             c->slab_B = std::max<int64_t>(64, (int64_t)((double)B * f));
         }
     }
+    if (c->snap_prev_valid && c->gather_j >= 2 && c->cfg.update_rule == 1) {
+        const int64_t range = c->hist_range[(c->gather_j - 2) & 3];
+        if (range > 0 && sl.cnt[3] >= c->snap_prev[3]) c->pairs_per_photon = (double)(sl.cnt[3] - c->snap_prev[3]) / (double)range;
+    }
     memcpy(c->snap_prev, sl.cnt, sizeof c->snap_prev);
     c->snap_prev_valid = 1;
     return 0;
@@ -1558,6 +1564,7 @@ static int deposit_tiles(sppm_ctx* c)
     tp.g = g;
     tp.cluster_d = c->gs.cluster_d;
     tp.veto = c->veto_dev;
+    c->hist_range[c->gather_j & 3] = range;
     c->gather_j++;
     const int n_dep_tiles = (c->n_own_pix + DEP_TILE - 1) / DEP_TILE;  // DEP_H hitpoints per lane
     hipLaunchKernelGGL(k_deposit_plan, dim3(nblk(n_dep_tiles, 4)), dim3(256), 0, st, c->hp, BS.cell_start, tp, n_dep_tiles, (uint32_t)c->dep_chunk, c->d_items_raw, c->d_n_pieces, c->d_est, c->d_item_q,
@@ -1569,7 +1576,18 @@ static int deposit_tiles(sppm_ctx* c)
     HIPCHK(hipEventRecord(c->ev_stat[c->stat_w], st));
     c->stat_w ^= 1; c->stat_n++;
     c->est_valid = 0;  // (the estimates of the ordered gather's plan are not made here)
-    const int blocks = std::max(1, std::min(nblk(n_dep_tiles, 4) * 4, (int)env_i64("SPPM_DEP_BLOCKS", 256 * 3)));
+    // Persistent workgroups: three of the four wavefront slots of every SIMD while the deposit is the pass's long pole
+    // (the first passes of a render: ~2800 pairs examined per photon at 1080p), down to 2.25 of them once it is not
+    // (~1600 pairs per photon from pass ~100 on): what runs beside the kernel -- the eye pass of the next pass with its
+    // sort, the tracer, the binning -- gets one workgroup slot per CU next to three resident deposit workgroups, and late
+    // in a render the next deposit waits for that eye pass, not for this kernel.  Measured (photons/s at 20 / 256
+    // passes): 768 workgroups 267M / 305M, 704 266M / 310M, 640 260M / 313M, 576 249M / 317M, 512 237M / 313M.
+    int dep_blocks = 256 * 3;
+    if (c->pairs_per_photon > 0.0) {
+        const double t = std::min(1.0, std::max(0.0, (c->pairs_per_photon - c->dep_light) / (c->dep_heavy - c->dep_light)));
+        dep_blocks = 576 + 64 * (int)std::lround(3.0 * t);
+    }
+    const int blocks = std::max(1, std::min(nblk(n_dep_tiles, 4) * 4, (int)env_i64("SPPM_DEP_BLOCKS", dep_blocks)));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->timing) { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventRecord(e0, st)); }
     const bool stamps = getenv("SPPM_STAMPS") != nullptr;
