@@ -6,7 +6,7 @@
 //     hp_pos[3][P] hp_nrm[3][P] hp_w[3][P] hp_flux[3][P] ld[3][P]  (f64)
 //     hp_r2[P] hp_dist[P] (f64)  hp_n[P] hp_obj[P] hp_valid[P] (i32)
 //     rule 1 only: hp_phi[3][P] hp_tau[3][P] hp_nd[P] (f64) hp_madd[P] (i32)
-//   photon-hit records, SoA: key[R] (u64: photon<<16 | depth<<1 | orient), f[9][Rcap] (position,
+//   photon-hit records, SoA: key[R] (u64: photon<<20 | depth<<1 | orient), f[9][Rcap] (position,
 //     geometric normal, flux).  Traced into the *unsorted* arrays by atomic append, then
 //     counting-sorted by hash-grid bucket into the *sorted* arrays each batch.
 //
