@@ -95,6 +95,7 @@ struct sppm_ctx {
     void* d_sort_tmp; size_t sort_tmp_bytes;
     uint32_t *d_est, *d_items; unsigned long long* d_items_raw; unsigned int* d_item_q; uint8_t* d_n_pieces; unsigned long long* d_est_sum; uint8_t* d_ext_bin; int est_valid;  // d_item_q: [0] items [1] queue head [2..33] per cost class
     double split_factor, est_per_photon; int64_t est_range;
+    int64_t hist_est_range, stat_est_range[2];  // photons of the batch whose estimates the statistics (and each pinned slot) hold
     int64_t batch_min; double batch_growth;  // per-photon rule: first batch and growth of the batches with the photons applied (batch_size)
     double fx_scale;          // per-pass rule: fixed point of the deposits (sppm_deposit.hpp), a power of two
     double cell_factor_dep;   // per-pass rule: cell size of the record grid as a share of the median tile extent
@@ -585,7 +586,7 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
         c->sort_tmp_bytes = 0; c->d_sort_tmp = nullptr; c->order_valid = 0;
         TRY(dev_alloc(c, &c->d_est, (size_t)c->n_owned + 1)); TRY(dev_alloc(c, &c->d_items, (size_t)c->n_owned * 64 + 64, false)); TRY(dev_alloc(c, &c->d_items_raw, (size_t)c->n_owned * 64 + 64, false));
         TRY(dev_alloc(c, &c->d_item_q, 2 + 2 * ITEM_CLASSES)); TRY(dev_alloc(c, &c->d_n_pieces, (size_t)c->n_owned + 1)); TRY(dev_alloc(c, &c->d_est_sum, 1)); TRY(dev_alloc(c, &c->d_ext_bin, (size_t)c->n_owned + 1)); c->est_valid = 0;
-        c->split_factor = 4.0; c->est_per_photon = 0.0; c->est_range = 0;
+        c->split_factor = 4.0; c->est_per_photon = 0.0; c->est_range = 0; c->hist_est_range = 0; c->stat_est_range[0] = c->stat_est_range[1] = 0;
         { const char* e = getenv("SPPM_SPLIT_FACTOR"); if (e && *e) c->split_factor = atof(e); }
         if (c->n_own_pix > 0) {
             if (rocprim::radix_sort_pairs<HpSortConfig>(nullptr, c->sort_tmp_bytes, c->d_hp_keys, c->d_hp_keys_out, c->d_own_pix, c->d_order,
@@ -1300,7 +1301,9 @@ static int stats_launch(sppm_ctx* c)
         hipLaunchKernelGGL(k_tile_extent, dim3(nblk(c->n_owned, 4)), dim3(256), 0, st, c->hp, tp, c->d_ext_bin);
         hipLaunchKernelGGL(k_tile_hist, dim3(1), dim3(1024), 0, st, c->d_ext_bin, c->est_valid ? c->d_est : (const uint32_t*)nullptr, c->n_owned, c->d_stats);
         HIPCHK(hipGetLastError());
+        c->hist_est_range = c->est_valid ? c->est_range : 0;  // the batch whose plan wrote d_est
     }
+    c->stat_est_range[c->stat_w] = c->hist_est_range;
     hipLaunchKernelGGL(k_stat_snapshot, dim3(1), dim3(64), 0, st, c->d_stats, c->d_hp_bb, c->d_counters, c->d_stat_map + c->stat_w);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev_stat[c->stat_w], st));
@@ -1345,7 +1348,10 @@ static int stats_read(sppm_ctx* c)
         c->gs.cell = cell;
         c->gs.cluster_d = std::ldexp(1.0, med - 32);  // upper edge of the median tile extent
         c->gs.valid = 1;
-        if (c->est_valid && c->est_range > 0) c->est_per_photon = (double)hs.est_sum / (double)hs.live_tiles / (double)c->est_range;
+        // (per photon of the batch the estimates were made for -- batches differ in size, and the slot is read a batch or
+        // two after it was written: dividing by the latest batch's size made the split threshold of the next plan 10x too
+        // small or too large whenever a short batch at the end of a pass was followed by a long one)
+        if (c->stat_est_range[r] > 0) c->est_per_photon = (double)hs.est_sum / (double)hs.live_tiles / (double)c->stat_est_range[r];
     } else if (!c->gs.valid) {  // no live hitpoint yet: any grid will do
         for (int k = 0; k < 3; k++) { c->gs.lo[k] = 0.0; c->gs.dims[k] = 1; }
         c->gs.ncells = 1; c->gs.cell = 1.0; c->gs.cluster_d = 1.0; c->gs.valid = 1;
