@@ -1,7 +1,7 @@
 """Time of passes with the reference's K = 10000 enforced at 1080p (both rules) and what the filter lets through.
     SPPM_DEBUG=1 python tools/kcap_time.py [passes]"""
-import sys, time
-sys.path.insert(0, ".")
+import os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
 from raytracer_amd import sppm
 W, H, M, passes = 1920, 1080, 1_000_000, int(sys.argv[1]) if len(sys.argv) > 1 else 3
