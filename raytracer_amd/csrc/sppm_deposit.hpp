@@ -61,6 +61,10 @@ __device__ __forceinline__ bool dep_load_tile(const HpArrays& hp, const TilePara
 // The hitpoints of cluster `c` of a tile, same rule in the plan and in the deposit: the first remaining hitpoint
 // (lowest h, then lowest lane) is the seed, hitpoints within cluster_d (max norm) of it join; the last cluster
 // takes whatever is left.  remaining[h] = ballot of the hitpoints not yet in a cluster.
+// (Round 3: clusters also split by normal -- a tile at an edge of the scene holds hitpoints of two surfaces, and as one
+// cluster none of its staged records can be classified for all hitpoints at once, 40 % of all full-test records at
+// 1080p -- halved the full-test records and the kernel's time by 1 %, and gave it back in the plan, which then loads
+// the normals too: 269M photons/s against 271M without.  Dropped.)
 __device__ __forceinline__ void dep_next_cluster(unsigned long long (&remaining)[DEP_H], int c, const DepTile& t, int lane, double cluster_d, bool (&inc)[DEP_H])
 {
     int sh = 0;
@@ -264,6 +268,9 @@ __global__ void __launch_bounds__(256) k_items_place(const unsigned long long* _
 #endif
 #define DEP_ATTR __attribute__((amdgpu_waves_per_eu(DEP_WAVES, DEP_WAVES)))
 #define DEP_FLUSH_ROWS 2048  // staged rows after which the double sums move to the 64-bit integers (2048 x 2^41 = 2^52)
+#ifndef DEP_NEAR_MAX
+#define DEP_NEAR_MAX 1e-4  // third class of staged records: largest G as a share of the cluster's largest squared radius (k_deposit_tiles)
+#endif
 #define DEP_ROWS 64  // staged records per wavefront: one group of candidates at a time, processed while the next group's loads are in flight
 // VETO: the reference's K cap is enforced (sppm_cap.hpp): a pair the capped kd search dropped is in tp.veto and is not
 // deposited (src/stochastic_ppm.h:425-427 hand gahter_max_photon_num to the same SearchNearest as src/sppm2.h).
@@ -282,6 +289,7 @@ __global__ void __launch_bounds__(256) DEP_ATTR k_deposit_tiles(HpArrays hp, Rec
     const double thr = tp.gather_r2 * 0.01;
     const double band_rel = 1e-9 + 8e-15 / thr;
     const double thr2_lo = thr * thr * (1.0 - band_rel), thr2_hi = thr * thr * (1.0 + band_rel);
+    const double inv_thr2_up = (1.0 / thr2_lo) * (1.0 + 4e-9);  // x this >= x / (thr2_lo (1 - 1e-9)), with room for the roundings
     const unsigned int n_items = q[0];
     const unsigned int n_waves = gridDim.x * 4u;
 #define DSTAMP() (STAMPS ? (unsigned long long)__builtin_amdgcn_s_memtime() : 0ull)
@@ -404,16 +412,26 @@ __global__ void __launch_bounds__(256) DEP_ATTR k_deposit_tiles(HpArrays hp, Rec
     const double m2x = -2.0 * hcx, m2y = -2.0 * hcy, m2z = -2.0 * hcz;
     const double hh = fma(hcz, hcz, fma(hcy, hcy, hcx * hcx));
     double lo_c = -INFINITY, hi_c = -INFINITY;  // a lane outside the cluster: never inside, never too close to call
+    double gl = 0.0;  // the value c of a pair is within E of d2 - hh: c - G > gl = E - hh guarantees d2 > G (third class, below)
     if (DEP_H == 1) {
         const double Hm = sqrt(wave_max_d(inc[0] ? hh : 0.0)), Qm = sqrt(bex * bex + bey * bey + bez * bez) + R.rmax;
         const double E = 1e-13 * (Hm + Qm) * (Hm + Qm);
         if (inc[0]) { lo_c = (lim_lo[0] - hh) - E; hi_c = (lim_hi[0] - hh) + E; }
+        gl = E - hh;
     }
+    // Third class of staged records ("near"): the normal test passes for the whole cluster, but the record lies inside
+    // the cluster's box or so close to it that the flatness test cannot be decided from the box alone.  For the whole
+    // cluster |g.(h - q)| <= f_hi, so the flatness test of a PAIR passes once its own squared distance exceeds
+    // G = f_hi^2 / thr^2 (margins as for the other bounds) -- one subtraction and one comparison more than the
+    // distance-only test; a pair at or below G (for a flat cluster G is ~1e-10: a record on top of a hitpoint) is
+    // decided by the reference's expressions from the record itself.  Only records whose G is a negligible share of
+    // the search area take this class.
+    const double g_max = pin_scalar_d(DEP_NEAR_MAX * rmax2);
     st_count += DSTAMP() - ts_setup;
     unsigned int c_sel = 0, c_round = 0;
     unsigned long long c_pairs = 0;
-    unsigned long long d_easy = 0, d_full = 0;  // diagnostic build: staged records by class
-    int sel_n = 0, n_easy = 0, n_full = 0;
+    unsigned long long d_easy = 0, d_full = 0, d_near = 0, d_near_slow = 0;  // diagnostic build: staged records by class
+    int sel_n = 0, n_easy = 0, n_near = 0, n_full = 0;
     // iterator over the list in groups of 64 entries
     int qbase = -64;
     unsigned int voff = 0, cbase = 0, i_end = 0;
@@ -475,7 +493,8 @@ __global__ void __launch_bounds__(256) DEP_ATTR k_deposit_tiles(HpArrays hp, Rec
             // can only accept such records), sort it by class (see above: dropped / distance test only / full test)
             // while each lane still holds its record in registers, compact it into the staging rows -- "easy" records
             // from row 0 up, the others from row 63 down -- and start the loads of the next group
-            bool in = false, easy = false;
+            bool in = false, easy = false, near = false;
+            double G = 0.0;
             if (p_has) {
                 const double nx = fmax(fmax(R.bx0 - p0, p0 - R.bx1), 0.0), ny = fmax(fmax(R.by0 - p1, p1 - R.by1), 0.0), nz = fmax(fmax(R.bz0 - p2, p2 - R.bz1), 0.0);
                 const double dmin2 = nx * nx + ny * ny + nz * nz;
@@ -488,27 +507,32 @@ __global__ void __launch_bounds__(256) DEP_ATTR k_deposit_tiles(HpArrays hp, Rec
                     const double spread = fabs(p3) * bex + fabs(p4) * bey + fabs(p5) * bez;
                     const double f_hi = (sc + spread) * (1.0 + 1e-9), f_lo = fmax(sc - spread, 0.0) * (1.0 - 1e-9);
                     const bool rej = nd + ndev < 1e-3 - 1e-9 || f_lo * f_lo > thr2_hi * dmax2 * (1.0 + 1e-9);
-                    easy = !rej && nd - ndev > 1e-3 + 1e-9 && dmin2 > 0.0 && f_hi * f_hi < thr2_lo * dmin2 * (1.0 - 1e-9);
+                    const bool n_all = nd - ndev > 1e-3 + 1e-9;
+                    easy = !rej && n_all && dmin2 > 0.0 && f_hi * f_hi < thr2_lo * dmin2 * (1.0 - 1e-9);
+                    G = (f_hi * f_hi) * inv_thr2_up;
+                    near = !rej && !easy && n_all && G < g_max;
                     in = !rej;
                 }
             }
-            const unsigned long long m_e = ballot64(in && easy), m_f = ballot64(in && !easy);
+            const unsigned long long m_e = ballot64(in && easy), m_n = ballot64(in && near), m_f = ballot64(in && !easy && !near);
             if (in) {
-                double* row = s_row[wv][easy ? (int)mbcnt64(m_e) : DEP_ROWS - 1 - (int)mbcnt64(m_f)];
+                double* row = s_row[wv][easy ? (int)mbcnt64(m_e) : (near ? __popcll(m_e) + (int)mbcnt64(m_n) : DEP_ROWS - 1 - (int)mbcnt64(m_f))];
                 const double f6 = p6, f7 = p7, f8 = p8;  // fixed point already (k_grid_scatter): integer-valued doubles
-                if (easy) {
+                if (easy || near) {
                     const double qx = p0 - bcx, qy = p1 - bcy, qz = p2 - bcz;
                     row[0] = qx; row[1] = qy; row[2] = qz; row[3] = fma(qz, qz, fma(qy, qy, qx * qx));
-                    row[4] = f6; row[5] = f7; row[6] = f8; row[7] = p0; row[8] = p1; row[9] = p2;
+                    row[4] = f6; row[5] = f7; row[6] = f8;
+                    if (easy) { row[7] = p0; row[8] = p1; row[9] = p2; }
+                    else { row[7] = G; row[8] = __longlong_as_double((long long)p_r); }  // (the record's place: a pair at or below G reads it again)
                 } else {
                     row[0] = p0; row[1] = p1; row[2] = p2; row[3] = p3; row[4] = p4; row[5] = p5;
                     row[6] = f6; row[7] = f7; row[8] = f8;
                 }
                 if (KEYS) row[ROW - 1] = __longlong_as_double((long long)p_key);
             }
-            n_easy = __popcll(m_e); n_full = __popcll(m_f);
-            sel_n = n_easy + n_full;
-            if (STAMPS) { d_easy += (unsigned long long)n_easy; d_full += (unsigned long long)n_full; }
+            n_easy = __popcll(m_e); n_near = __popcll(m_n); n_full = __popcll(m_f);
+            sel_n = n_easy + n_near + n_full;
+            if (STAMPS) { d_easy += (unsigned long long)n_easy; d_full += (unsigned long long)n_full; d_near += (unsigned long long)n_near; }
             const unsigned long long t1 = DSTAMP();
             DEP_ISSUE()
             if (STAMPS) { st_append += t1 - t0; st_issue += DSTAMP() - t1; }
@@ -519,7 +543,7 @@ __global__ void __launch_bounds__(256) DEP_ATTR k_deposit_tiles(HpArrays hp, Rec
         // depend on the orientation of the normal) and the acceptance test of src/stochastic_ppm.h:441-445
         __builtin_amdgcn_wave_barrier();
         c_sel += (unsigned int)sel_n; c_pairs += (unsigned long long)sel_n * R.n_inc; c_round++;
-        const int ne_u = __builtin_amdgcn_readfirstlane(n_easy), nf_u = __builtin_amdgcn_readfirstlane(n_full);
+        const int ne_u = __builtin_amdgcn_readfirstlane(n_easy), nn_u = __builtin_amdgcn_readfirstlane(n_near), nf_u = __builtin_amdgcn_readfirstlane(n_full);
         if (rows_unflushed + (unsigned int)sel_n > DEP_FLUSH_ROWS) DEP_FLUSH()
         rows_unflushed += (unsigned int)sel_n;
         // rows [0, n_easy): the normal and flatness tests pass for the whole cluster, the distance test alone decides.
@@ -560,6 +584,41 @@ __global__ void __launch_bounds__(256) DEP_ATTR k_deposit_tiles(HpArrays hp, Rec
                 if (!(c0 < lo_c) && !(c0 > hi_c)) {
                     const double e = len2(mk(t.x[0], t.y[0], t.z[0]) - mk(row[7], row[8], row[9]));
                     if (inc[0] && (e < tp.gather_r2) && (e <= t.r2[0])) DEP_TAKE(row)
+                }
+            }
+        }
+        // rows [n_easy, n_easy + n_near): the distance test and the pair's own flatness bound (see g_max above)
+        if (nn_u > 0) {
+            unsigned long long und2 = 0ull;
+            for (int tn = ne_u; tn < ne_u + nn_u; tn++) {
+                const double* r0 = s_row[wv][tn];
+                const double c0 = fma(m2z, r0[2], fma(m2y, r0[1], fma(m2x, r0[0], r0[3])));
+                const bool acc = c0 < lo_c && c0 - r0[7] > gl;
+                und2 |= ~(ballot64(acc) | ballot64(c0 > hi_c));
+                if (acc) DEP_TAKE(r0)
+            }
+            if ((und2 & ballot64(true)) != 0ull) {
+                if (STAMPS) d_near_slow++;
+                for (int tn = ne_u; tn < ne_u + nn_u; tn++) {
+                    const double* row = s_row[wv][tn];
+                    const double c0 = fma(m2z, row[2], fma(m2y, row[1], fma(m2x, row[0], row[3])));
+                    if (!(c0 < lo_c && c0 - row[7] > gl) && !(c0 > hi_c)) {
+                        // the reference's operation order, from the record itself
+                        const double* rp = rec.f + (size_t)REC_ROW * (size_t)__double_as_longlong(row[8]);
+                        const d3 qq = mk(rp[0], rp[1], rp[2]), g0 = mk(rp[3], rp[4], rp[5]);
+                        const d3 dir = mk(t.x[0], t.y[0], t.z[0]) - qq;
+                        const double d2 = len2(dir);
+                        const bool o = inc[0] && (d2 < tp.gather_r2) && (d2 <= t.r2[0]) && (dot(hn[0], g0) > 1e-3);
+                        const double s1 = dot(g0, dir);
+                        const double l2 = s1 * s1, rhs = thr * thr * d2;
+                        const double band = rhs * band_rel;
+                        bool flat = l2 < rhs - band;
+                        if (o && !flat && !(l2 > rhs + band)) {
+                            const double dt = dot(g0, dir / sqrt(d2));  // NaN at d2 == 0: rejected as in the reference
+                            flat = fabs(dt) <= thr;
+                        }
+                        if (o && flat) DEP_TAKE(row)
+                    }
                 }
             }
         }
@@ -634,7 +693,7 @@ __global__ void __launch_bounds__(256) DEP_ATTR k_deposit_tiles(HpArrays hp, Rec
         if (c_sel) atomicAdd(&counters[5], (unsigned long long)c_sel);
         if (c_round) atomicAdd(&counters[6], (unsigned long long)c_round);
         atomicAdd(&counters[7], 1ull);
-        if (STAMPS) { atomicAdd(&counters[22], d_easy); atomicAdd(&counters[15], d_full); }
+        if (STAMPS) { atomicAdd(&counters[22], d_easy); atomicAdd(&counters[15], d_full); atomicAdd(&counters[8], d_near); atomicAdd(&counters[9], d_near_slow); }
     }
     __builtin_amdgcn_wave_barrier();
     st_flush += DSTAMP() - tf0;

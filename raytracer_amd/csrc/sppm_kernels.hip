@@ -1602,6 +1602,7 @@ static int deposit_tiles(sppm_ctx* c)
     const bool dep_wg = env_i64("SPPM_DEP_WG", 0) != 0 && DEP_H == 1;
     if (stamps) {
         HIPCHK(hipMemsetAsync(c->d_counters + 15, 0, 9 * sizeof(unsigned long long), st));
+        HIPCHK(hipMemsetAsync(c->d_counters + 8, 0, 2 * sizeof(unsigned long long), st));
         hipLaunchKernelGGL((k_deposit_tiles<false, true>), dim3(blocks), dim3(256), 0, st, c->hp, BS.rec_s, BS.cell_start, tp, c->d_items, c->d_item_q, c->d_counters, c->d_err);
         unsigned long long t[24];
         HIPCHK(hipMemcpyAsync(t, c->d_counters, sizeof t, hipMemcpyDeviceToHost, st));
@@ -1609,7 +1610,7 @@ static int deposit_tiles(sppm_ctx* c)
         const double tot = (double)(t[16] + t[17] + t[18] + t[19] + t[20] + t[21]);
         fprintf(stderr, "[sppm] deposit: items %llu, shares of wave cycles: setup %.1f%% count %.1f%% issue %.1f%% append %.1f%% (of it waiting for the group's loads %.1f%%) process %.1f%% flush %.1f%%; grid %dx%dx%d\n", t[7],
                 100.0 * t[16] / tot, 100.0 * t[17] / tot, 100.0 * t[18] / tot, 100.0 * t[19] / tot, 100.0 * t[23] / tot, 100.0 * t[20] / tot, 100.0 * t[21] / tot, g.nx, g.ny, g.nz);
-        fprintf(stderr, "[sppm]   staged records by class: distance test only %llu, full test %llu (records rejected for the whole cluster are not staged)\n", t[22], t[15]);
+        fprintf(stderr, "[sppm]   staged records by class: distance test only %llu, distance + pair flatness bound %llu (groups that needed the exact expressions: %llu), full test %llu (records rejected for the whole cluster are not staged)\n", t[22], t[8], t[9], t[15]);
     } else if (c->veto_dev.n != nullptr) {  // the K cap acts on this batch: the pairs it dropped are withheld
         if (c->tap_cap > 0) hipLaunchKernelGGL((k_deposit_tiles<true, false, true>), dim3(blocks), dim3(256), 0, st, c->hp, BS.rec_s, BS.cell_start, tp, c->d_items, c->d_item_q, c->d_counters, c->d_err);
         else hipLaunchKernelGGL((k_deposit_tiles<false, false, true>), dim3(blocks), dim3(256), 0, st, c->hp, BS.rec_s, BS.cell_start, tp, c->d_items, c->d_item_q, c->d_counters, c->d_err);
