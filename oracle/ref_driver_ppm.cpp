@@ -12,7 +12,7 @@
 // pass (as for sppm2.h).  render() also writes image files every few photons and offers no tap.
 // Determinism: std::random_device::_M_getval is interposed to return a counter (seed of every mt19937).
 //
-// usage: ref_driver_ppm outdir W H photons traced gather_r2 gather_k [seed_eye seed_photon supersamples]
+// usage: ref_driver_ppm outdir W H photons traced gather_r2 gather_k [seed_eye seed_photon supersamples samples]
 #include <algorithm>
 #include <climits>
 #include <cmath>
@@ -53,12 +53,10 @@ static void dump(const std::string& name, const std::vector<T>& v)
 }
 static void push3(std::vector<double>& v, const Vec& a) { v.push_back(a.x); v.push_back(a.y); v.push_back(a.z); }
 
-typedef std::tuple<int, double, double, double> HpKey;  // (pixel, position): CreateKDtree reorders the vector
-static HpKey key_of(const ppm::ProgressiveIntersection& p) { return HpKey(p.index, p.position.x, p.position.y, p.position.z); }
 
 int main(int argc, char** argv)
 {
-    if (argc < 8) { fprintf(stderr, "usage: %s outdir W H photons traced gather_r2 gather_k [seed_eye seed_photon supersamples]\n", argv[0]); return 2; }
+    if (argc < 8) { fprintf(stderr, "usage: %s outdir W H photons traced gather_r2 gather_k [seed_eye seed_photon supersamples samples]\n", argv[0]); return 2; }
     g_out = argv[1];
     const int W = atoi(argv[2]), H = atoi(argv[3]), P = W * H;
     const int photon_num = atoi(argv[4]), traced = atoi(argv[5]);
@@ -66,7 +64,8 @@ int main(int argc, char** argv)
     const int gather_k = atoi(argv[7]);
     const unsigned seed_eye = argc > 8 ? (unsigned)strtoul(argv[8], 0, 10) : 1000u;
     const unsigned seed_photon = argc > 9 ? (unsigned)strtoul(argv[9], 0, 10) : 2000u;
-    const int samples = 1, supersamples = argc > 10 ? atoi(argv[10]) : 1, spp = samples * supersamples * supersamples;  // samples > 1 repeats one ray: identical hitpoints
+    // samples > 1 repeats one ray (src/progressive_photonmapping.h:741-757): identical hitpoints, as src/main.cpp:79 runs it
+    const int samples = argc > 11 ? atoi(argv[11]) : 1, supersamples = argc > 10 ? atoi(argv[10]) : 1, spp = samples * supersamples * supersamples;
 
     std::streambuf* cout_buf = std::cout.rdbuf();
     std::ofstream devnull("/dev/null");
@@ -100,15 +99,14 @@ int main(int argc, char** argv)
         }
     auto& pts = point_map.GetData();
     const size_t Hn = pts.size();
-    std::map<HpKey, int> id_of;
+    std::vector<int> id_at(Hn);  // creation id of the hitpoint at each place of the vector once CreateKDtree has reordered it
     {   // hitpoints in creation order; B1: photon_count is unset, the call site passes 0 (:525)
         std::vector<int32_t> hp_i;
         std::vector<double> hp_f;
         for (size_t k = 0; k < Hn; k++) {
             auto& p = pts[k];
-            p.photon_count = 0;
+            p.photon_count = (int)k;  // the creation id rides through CreateKDtree in this field (identical samples make identical hitpoints); zeroed below
             p.accumulated_flux = Color();
-            if (!id_of.emplace(key_of(p), (int)k).second) { fprintf(stderr, "two hitpoints of one pixel at one position\n"); return 3; }
             hp_i.push_back(p.index); hp_i.push_back(p.intersection.object_id);
             hp_f.push_back(p.intersection.hitpoint.distance);
             push3(hp_f, p.position); push3(hp_f, p.intersection.hitpoint.normal);
@@ -125,7 +123,7 @@ int main(int argc, char** argv)
     point_map.CreateKDtree();
     {   // the order in which render() later walks the hitpoints (the vector was sorted in place)
         std::vector<int32_t> order;
-        for (auto& p : pts) order.push_back(id_of.at(key_of(p)));
+        for (size_t j = 0; j < Hn; j++) { id_at[j] = pts[j].photon_count; pts[j].photon_count = 0; order.push_back(id_at[j]); }
         dump("ppm_kd_order.bin", order);
     }
     {   // photon pass = update_photons (:618-640) minus its printing
@@ -141,8 +139,9 @@ int main(int argc, char** argv)
                 while (!(before == ph_sampler.engine_)) { before(); words++; }
                 words_per_photon.push_back(words);
                 std::vector<std::pair<int, int>> acc;
-                for (auto& p : pts) {
-                    const int id = id_of.at(key_of(p));
+                for (size_t j = 0; j < Hn; j++) {
+                    auto& p = pts[j];
+                    const int id = id_at[j];
                     if (p.photon_count != prev[id]) { acc.push_back({id, p.photon_count - prev[id]}); prev[id] = p.photon_count; }
                 }
                 std::sort(acc.begin(), acc.end());
@@ -159,8 +158,9 @@ int main(int argc, char** argv)
     {   // per-hitpoint state after the photons, by creation id
         std::vector<int32_t> st_n(Hn, -1);
         std::vector<double> st_f(4 * Hn, 0.0);
-        for (auto& p : pts) {
-            const int id = id_of.at(key_of(p));
+        for (size_t j = 0; j < Hn; j++) {
+            auto& p = pts[j];
+            const int id = id_at[j];
             st_n[id] = p.photon_count;
             st_f[4 * (size_t)id] = p.photon_radius_2;
             st_f[4 * (size_t)id + 1] = p.accumulated_flux.x; st_f[4 * (size_t)id + 2] = p.accumulated_flux.y; st_f[4 * (size_t)id + 3] = p.accumulated_flux.z;

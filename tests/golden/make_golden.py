@@ -90,15 +90,15 @@ def run(tag, w, h, photons, passes, traced, r2, k, seed_eye, seed_photon, full, 
         print(f"wrote {path}: {os.path.getsize(path) / 1024:.0f} KiB")
 
 
-def run_ppm(tag, w, h, photons, traced, r2, k, seed_eye, seed_photon, supersamples):
+def run_ppm(tag, w, h, photons, traced, r2, k, seed_eye, seed_photon, supersamples, samples=1):
     """Classic progressive photon mapping (src/progressive_photonmapping.h) through oracle/ref_driver_ppm.cpp."""
     exe = os.path.join(ORACLE, "_ref", "ref_driver_ppm")
     with tempfile.TemporaryDirectory() as d:
         subprocess.check_call([exe, d, str(w), str(h), str(photons), str(traced), repr(float(r2)), str(k),
-                               str(seed_eye), str(seed_photon), str(supersamples)])
+                               str(seed_eye), str(seed_photon), str(supersamples), str(samples)])
         P = w * h
         hp_i = rd(d, "ppm_hp_i.bin", np.int32).reshape(-1, 2)
-        out = dict(meta=np.array([w, h, photons, traced, k, seed_eye, seed_photon, supersamples], np.int64),
+        out = dict(meta=np.array([w, h, photons, traced, k, seed_eye, seed_photon, supersamples], np.int64), samples=np.array([samples], np.int64),
                    gather_r2=np.array([r2], np.float64),
                    hp_pix=hp_i[:, 0].copy(), hp_obj=hp_i[:, 1].astype(np.int8),
                    hp_f=rd(d, "ppm_hp_f.bin", np.float64).reshape(-1, 11),
@@ -178,6 +178,8 @@ def main():
     # tag, W, H, photons, per-photon-traced, search r^2 (= InitialRadius, main.cpp:76-77), K cap, seeds, supersamples
     run_ppm("64x48", 64, 48, 20000, 4096, 25.0, 100000, 1000, 2000, 1)
     run_ppm("48x36_ss2_r5", 48, 36, 30000, 2048, 5.0, 100000, 31, 77, 2)
+    # identical samples per pixel (src/main.cpp:79 runs 100): duplicate hitpoints, equal keys in every range of the tree, and a binding K
+    run_ppm("32x24_s2_k6", 32, 24, 10000, 10000, 25.0, 6, 1000, 2000, 1, samples=2)
     # the per-pass rule (src/stochastic_ppm.h): tag, W, H, photons/pass, passes, per-photon-traced, search r^2 (0 = running
     # max of the hitpoint radii), K cap, seeds, stream layout (0 = sppm2's streams, 1 = render()'s own), stride
     run_pp("64x48", 64, 48, 20000, 3, 4096, 0.0, 100000, 1000, 2000, 0, 1)

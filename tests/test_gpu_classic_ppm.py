@@ -116,12 +116,14 @@ def test_classic_ppm_matches_oracle_bit_for_bit(w, h, ss, r2, photons, monkeypat
             monkeypatch.delenv(k)
 
 
-@pytest.mark.parametrize("tag", ["64x48", "48x36_ss2_r5"])
+@pytest.mark.parametrize("tag", ["64x48", "48x36_ss2_r5", "32x24_s2_k6"])
 def test_classic_ppm_renders_the_reference_image(golden, tag, tmp_path):
+    """(32x24_s2_k6: two identical samples per pixel and K = 6 -- duplicate hitpoints, equal keys in the tree, equal
+    distances in the heap, the cap binding: which twin the cap drops is the reference's choice)"""
     g = golden("ppm_" + tag)
     w, h, photons, traced, k, se, sp, ss = [int(x) for x in g["meta"]]
     r2 = float(g["gather_r2"][0])
-    cfg = sppm.make_config(w, h, supersamples=ss, gather_radius2=r2, initial_radius2=r2, gather_max=k, seed_eye=se, seed_photon=sp,
+    cfg = sppm.make_config(w, h, samples=int(g["samples"][0]) if "samples" in g else 1, supersamples=ss, gather_radius2=r2, initial_radius2=r2, gather_max=k, seed_eye=se, seed_photon=sp,
                            photons_per_pass=photons, sampler=1, algorithm=1)
     ctx = sppm.SppmContext(cfg)
     assert ctx.n_hitpoints == len(g["hp_pix"]), "length of the hitpoint list"

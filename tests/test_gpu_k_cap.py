@@ -86,6 +86,25 @@ def test_classic_ppm_with_binding_cap():
     ctx.close()
 
 
+def test_classic_ppm_identical_samples_tie_in_the_tree():
+    """samples = 2 puts two hitpoints at EVERY position (src/main.cpp:79 runs 100 identical samples): every range of the
+    tree holds equal keys, whose order std::sort decides, and the heap holds equal distances, of which libstdc++'s
+    pop_heap decides which one the cap drops.  Equal to the oracle, which the compiled reference's run with the same
+    set-up pins (ref_ppm_32x24_s2_k6: the GPU reproduces that run too, tests/test_gpu_classic_ppm.py)."""
+    w, h, photons, K = 32, 24, 10000, 6
+    ctx = sppm.SppmContext(sppm.make_config(w, h, samples=2, photons_per_pass=photons, gather_radius2=25.0, initial_radius2=25.0, algorithm=1, gather_max=K))
+    orc = ol.PpmOracle(ol.make_params(w, h, samples=2, sampler=1, math=1, photons_per_pass=photons, gather_radius2=25.0, initial_radius2=25.0, gather_max=K),
+                       ol.make_spheres(CORNELL_SPHERES))
+    assert ctx.n_hitpoints == orc.eye_pass()
+    ctx.eye_pass(0); ctx.photon_pass(0, photons); orc.photon_pass(0, photons)
+    ctx.check()
+    s, o = ctx.hitpoints(), orc.state()
+    for k in ("n", "r2", "flux"):
+        _same(s[k], o[k], f"state {k}")
+    assert ctx.counters()["cap_dropped_pairs"] > 0
+    ctx.close()
+
+
 def test_cap_switched_off_is_the_uncapped_set():
     W, H, M = 64, 48, 20000
     res = {}

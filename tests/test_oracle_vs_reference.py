@@ -87,14 +87,15 @@ def test_sppm_passes(golden, tag):
         assert hashlib.sha256(ol.ppm_file(img, w, h)).digest() == g["final_ppm_sha256"].tobytes()
 
 
-@pytest.mark.parametrize("tag", ["64x48", "48x36_ss2_r5"])
+@pytest.mark.parametrize("tag", ["64x48", "48x36_ss2_r5", "32x24_s2_k6"])
 def test_classic_ppm(golden, tag):
     """src/progressive_photonmapping.h: create_point's hitpoint list, the kd-sorted order render() sums in, the
     photons' accepted hitpoint sets, radii/counts/flux after all photons, the image and the .hdr bytes."""
     g = golden("ppm_" + tag)
     w, h, photons, traced, k, se, sp, ss = [int(x) for x in g["meta"]]
     r2 = float(g["gather_r2"][0])
-    p = ol.make_params(w, h, supersamples=ss, sampler=0, math=0, gather_radius2=r2, initial_radius2=r2, gather_max=k,
+    samples = int(g["samples"][0]) if "samples" in g else 1
+    p = ol.make_params(w, h, samples=samples, supersamples=ss, sampler=0, math=0, gather_radius2=r2, initial_radius2=r2, gather_max=k,
                        seed_eye=se, seed_photon=sp, photons_per_pass=photons)
     o = ol.PpmOracle(p, ol.make_spheres(CORNELL_SPHERES))
     nh = o.eye_pass()
