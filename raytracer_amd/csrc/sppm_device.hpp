@@ -494,3 +494,55 @@ __device__ __forceinline__ bool glass(d3 dir, d3 n, d3 on, bool eye, bool& into,
     Re = R0 + (1.0 - R0) * dm_pow5(c);
     return true;
 }
+
+// ---- spatial order of the hitpoints (sort keys: k_hp_sortkeys in sppm_gather_tiles.hpp, and the eye pass itself) ----
+__device__ __forceinline__ unsigned long long ord_d(double v)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double undo_ord_d(unsigned long long o)
+{
+    const unsigned long long b = (o >> 63) ? (o & 0x7fffffffffffffffull) : ~o;
+    return __longlong_as_double((long long)b);
+}
+__device__ __forceinline__ unsigned long long spread3(unsigned long long x)  // 21 bits -> every third bit
+{
+    x &= 0x1fffffull;
+    x = (x | (x << 32)) & 0x1f00000000ffffull;
+    x = (x | (x << 16)) & 0x1f0000ff0000ffull;
+    x = (x | (x << 8)) & 0x100f00f00f00f00full;
+    x = (x | (x << 4)) & 0x10c30c30c30c30c3ull;
+    x = (x | (x << 2)) & 0x1249249249249249ull;
+    return x;
+}
+// Morton code, MORTON_BITS bits per axis over the bounding box (ties keep pixel order: the sort is stable);
+// invalid hitpoints sort last
+typedef uint32_t hp_key_t;
+#ifndef MORTON_BITS
+#define MORTON_BITS 10
+#endif
+#ifdef MORTON_INVALID_MAX
+#define MORTON_KEY_BITS (3 * MORTON_BITS)
+#define MORTON_INVALID (((hp_key_t)1u << (3 * MORTON_BITS)) - 1u)
+#else
+#define MORTON_KEY_BITS (3 * MORTON_BITS + 1)  // (+1: the invalid hitpoints' key)
+#define MORTON_INVALID ((hp_key_t)1u << (3 * MORTON_BITS))
+#endif
+#define MORTON_MAX ((double)((1 << MORTON_BITS) - 1))
+// the key of a valid hitpoint at (x, y, z): bb[0..2] = min, bb[3..5] = max of a bounding box (ordered ints); positions
+// outside the box clamp to its faces (any order of the hitpoints is a valid one: the box only has to be about right)
+__device__ __forceinline__ hp_key_t hp_morton_key(double x, double y, double z, const unsigned long long* __restrict__ bb)
+{
+    unsigned long long code = 0;
+    const double v[3] = {x, y, z};
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const double lo = undo_ord_d(bb[a]), hi = undo_ord_d(bb[3 + a]);
+        const double ext = hi - lo;
+        double f = ext > 0.0 ? (v[a] - lo) / ext * MORTON_MAX : 0.0;
+        f = f < 0.0 ? 0.0 : (f > MORTON_MAX ? MORTON_MAX : f);
+        code |= spread3((unsigned long long)f) << a;
+    }
+    return (hp_key_t)code;
+}

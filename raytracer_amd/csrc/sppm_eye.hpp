@@ -51,6 +51,10 @@ struct EyeParams {
     uint32_t* hcnt; const long long* hoff;
     // thin-lens camera: seed of the per-(pass, pixel) lens streams; reference-stream mode: this pass's lens draws
     uint32_t seed_lens; const double* lens_u;
+    // k_eye_pass only, all three or none: the bounding box of the hitpoints this pass leaves (bb_out, seeded by the caller)
+    // and their sort keys (keys_out, by image index), quantised over the box of the pass BEFORE (bb_prev) -- what
+    // k_hp_bbox and k_hp_sortkeys would do in two more launches and two more sweeps over the positions
+    const unsigned long long* bb_prev; unsigned long long* bb_out; uint32_t* keys_out;
 };
 
 __device__ __forceinline__ LensRng make_lens(const EyeParams& ep, int t, int index)
@@ -252,6 +256,34 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EYE_WA
         const int index = (ep.H - t / ep.W - 1) * ep.W + t % ep.W;
         XorShift rng = make_stream(ep.seed_eye, (uint64_t)ep.pass * (uint64_t)P + (uint64_t)index);
         eye_pixel<XorShift, true, GRID>(sc, ep, hp, out, t, rng, rays);
+    }
+    if (ep.keys_out) {  // (the same for every thread of the launch)
+        const double BIG = 1e300;
+        double lo[3] = {BIG, BIG, BIG}, hi[3] = {-BIG, -BIG, -BIG};
+        if (t < P) {
+            int index = (ep.H - t / ep.W - 1) * ep.W + t % ep.W;
+            asm volatile("" : "+v"(index));  // (see eye_path_step)
+            hp_key_t key = MORTON_INVALID;
+            if (out.valid[index]) {  // what this thread has just stored, or copied from the view before
+                const double x = out.pos[index], y = out.pos[P + index], z = out.pos[2 * P + index];
+                lo[0] = hi[0] = x; lo[1] = hi[1] = y; lo[2] = hi[2] = z;
+                key = hp_morton_key(x, y, z, ep.bb_prev);
+            }
+            ep.keys_out[index] = key;
+        }
+        __shared__ double s_lo[4][3], s_hi[4][3];
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            for (int off = 32; off > 0; off >>= 1) { lo[a] = fmin(lo[a], __shfl_xor(lo[a], off)); hi[a] = fmax(hi[a], __shfl_xor(hi[a], off)); }
+            if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6][a] = lo[a]; s_hi[threadIdx.x >> 6][a] = hi[a]; }
+        }
+        __syncthreads();
+        if (threadIdx.x < 3) {  // one pair of atomics per block and axis
+            const int a = threadIdx.x;
+            const double l = fmin(fmin(s_lo[0][a], s_lo[1][a]), fmin(s_lo[2][a], s_lo[3][a]));
+            const double h = fmax(fmax(s_hi[0][a], s_hi[1][a]), fmax(s_hi[2][a], s_hi[3][a]));
+            if (l <= h) { atomicMin(&ep.bb_out[a], ord_d(l)); atomicMax(&ep.bb_out[3 + a], ord_d(h)); }
+        }
     }
     // rays counter: one atomic per wave
     for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off);

@@ -55,16 +55,6 @@ __device__ __forceinline__ int grid_coord(double x, double o, double inv_c, int 
 __device__ __forceinline__ int tile_of_pixel(int p, int W, int tiles_x) { return ((p / W) >> 3) * tiles_x + ((p % W) >> 3); }
 
 // ---- spatial order of the hitpoints ------------------------------------------------------------------
-__device__ __forceinline__ unsigned long long ord_d(double v)
-{
-    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
-    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
-}
-__device__ __forceinline__ double undo_ord_d(unsigned long long o)
-{
-    const unsigned long long b = (o >> 63) ? (o & 0x7fffffffffffffffull) : ~o;
-    return __longlong_as_double((long long)b);
-}
 // bounding box of the valid hitpoints among pix[0..n): bb[0..2] = min, bb[3..5] = max (ordered ints)
 __global__ void k_hp_bbox(HpArrays hp, const int32_t* __restrict__ pix, int n, unsigned long long* __restrict__ bb)
 {
@@ -89,30 +79,6 @@ __global__ void k_hp_bbox(HpArrays hp, const int32_t* __restrict__ pix, int n, u
         if (l <= h) { atomicMin(&bb[a], ord_d(l)); atomicMax(&bb[3 + a], ord_d(h)); }
     }
 }
-__device__ __forceinline__ unsigned long long spread3(unsigned long long x)  // 21 bits -> every third bit
-{
-    x &= 0x1fffffull;
-    x = (x | (x << 32)) & 0x1f00000000ffffull;
-    x = (x | (x << 16)) & 0x1f0000ff0000ffull;
-    x = (x | (x << 8)) & 0x100f00f00f00f00full;
-    x = (x | (x << 4)) & 0x10c30c30c30c30c3ull;
-    x = (x | (x << 2)) & 0x1249249249249249ull;
-    return x;
-}
-// Morton code, MORTON_BITS bits per axis over the bounding box (ties keep pixel order: the sort is stable);
-// invalid hitpoints sort last
-typedef uint32_t hp_key_t;
-#ifndef MORTON_BITS
-#define MORTON_BITS 10
-#endif
-#ifdef MORTON_INVALID_MAX
-#define MORTON_KEY_BITS (3 * MORTON_BITS)
-#define MORTON_INVALID (((hp_key_t)1u << (3 * MORTON_BITS)) - 1u)
-#else
-#define MORTON_KEY_BITS (3 * MORTON_BITS + 1)  // (+1: the invalid hitpoints' key)
-#define MORTON_INVALID ((hp_key_t)1u << (3 * MORTON_BITS))
-#endif
-#define MORTON_MAX ((double)((1 << MORTON_BITS) - 1))
 __global__ void k_hp_sortkeys(HpArrays hp, const int32_t* __restrict__ pix, int n, const unsigned long long* __restrict__ bb,
                               hp_key_t* __restrict__ keys)
 {
@@ -120,15 +86,8 @@ __global__ void k_hp_sortkeys(HpArrays hp, const int32_t* __restrict__ pix, int 
     if (i >= n) return;
     const int p = pix[i], P = hp.P;
     if (!hp.valid[p]) { keys[i] = MORTON_INVALID; return; }
-    unsigned long long code = 0;
-    for (int a = 0; a < 3; a++) {
-        const double lo = undo_ord_d(bb[a]), hi = undo_ord_d(bb[3 + a]);
-        const double ext = hi - lo;
-        double f = ext > 0.0 ? (hp.pos[a * P + p] - lo) / ext * MORTON_MAX : 0.0;
-        f = f < 0.0 ? 0.0 : (f > MORTON_MAX ? MORTON_MAX : f);
-        code |= spread3((unsigned long long)f) << a;
-    }
-    keys[i] = (hp_key_t)code;
+    const hp_key_t code = hp_morton_key(hp.pos[p], hp.pos[P + p], hp.pos[2 * P + p], bb);
+    keys[i] = code;
 }
 
 // (slab, cell) bucket of every record of the batch

@@ -121,6 +121,7 @@ struct sppm_ctx {
     int chain_n, view_chain[2];
     hipStream_t eye_stream; hipEvent_t ev_eye_done, ev_eye_go;
     struct { int valid, pass; } pre_eye;  // an eye pass computed ahead of its call
+    int fuse_order;  // the eye pass makes the hitpoints' bounding box and sort keys itself where it can (eye_launch)
     int last_eye_pass;
     unsigned long long *d_rows_n, *h_rows_n; hipEvent_t ev_rows; int rows_pending; int64_t rows_cap;  // sppm_look_ahead_rows
     // Record exchange by destination (sppm_look_ahead_rows_to): with spatial ownership every rank knows every rank's
@@ -507,6 +508,7 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
     c->pre.valid = 0;
     c->ahead_depth = (int)std::max<int64_t>(1, std::min<int64_t>(NBUF - 1, env_i64("SPPM_AHEAD", NBUF - 1)));
     c->prefetch = (int)env_i64("SPPM_PREFETCH", 1);
+    c->fuse_order = (int)env_i64("SPPM_FUSE_ORDER", 1);
     if (c->sampler == 1) {
         c->prefetch = 0;  // a pass's photon stream offsets exist only once its photon pass has begun
     }
@@ -700,7 +702,7 @@ static EyeParams eye_params(const sppm_ctx* c, int32_t pass)
     ep.pass = pass; ep.seed_eye = c->cfg.seed_eye; ep.initial_r2 = c->cfg.initial_radius2; ep.double_nee = c->cfg.double_nee;
     ep.cnt = c->d_eye_cnt; ep.off = c->d_eye_off; ep.total = c->d_stream_total; ep.hcnt = c->d_hcnt; ep.hoff = c->d_hoff;
     ep.u = c->d_u_eye; ep.u_len = c->u_eye_len;
-    ep.seed_lens = c->cfg.seed_lens; ep.lens_u = nullptr;
+    ep.seed_lens = c->cfg.seed_lens; ep.lens_u = nullptr; ep.bb_prev = nullptr; ep.bb_out = nullptr; ep.keys_out = nullptr;
     return ep;
 }
 
@@ -868,6 +870,9 @@ static int eye_launch(sppm_ctx* c, int32_t pass, hipStream_t st)
     ep.pass = pass; ep.seed_eye = c->cfg.seed_eye; ep.initial_r2 = c->cfg.initial_radius2; ep.double_nee = c->cfg.double_nee;
     ep.u = nullptr; ep.u_len = 0; ep.cnt = nullptr; ep.off = nullptr; ep.total = nullptr; ep.hcnt = nullptr; ep.hoff = nullptr;
     ep.seed_lens = c->cfg.seed_lens; ep.lens_u = nullptr;
+    ep.bb_prev = nullptr; ep.bb_out = nullptr; ep.keys_out = nullptr;
+    const bool fuse_order = c->fuse_order && c->gather_mode && c->n_own_pix == (int)c->P && c->tile_stride <= 1 && !c->own_pending && c->algo == 0 && c->sampler == 0 && !c->dscene.n_cells &&
+                            c->view_chain[c->cur_view] >= 0;
     // the order chain that last read this view's positions must be done before the view is written again
     if (c->view_chain[nv] >= 0) HIPCHK(hipStreamWaitEvent(st, c->ev_order[c->view_chain[nv]], 0));
     if (c->algo == 1) {
@@ -881,7 +886,18 @@ static int eye_launch(sppm_ctx* c, int32_t pass, hipStream_t st)
             HIPCHK(hipMemsetAsync(c->d_eye_next, 0, sizeof(unsigned long long), st));
             hipLaunchKernelGGL(k_eye_pass_refill<1>, dim3(std::min(nblk(c->P, 256), 256 * 3)), dim3(256), scene_lds(c), st, scene_of(c), ep, c->hp, c->view[nv], c->d_eye_next, c->d_counters);
         }
-        else hipLaunchKernelGGL(k_eye_pass<0>, dim3(nblk(c->P, 256)), dim3(256), scene_lds(c), st, scene_of(c), ep, c->hp, c->view[nv], c->d_counters);
+        else {
+            // One GPU's whole image, and a pass before this one has left a bounding box: the eye pass makes the box and the
+            // sort keys itself (keys over the box of the pass before; any order of the hitpoints is a valid one).  Two
+            // launches and two sweeps over the positions fewer in the chain that the next gather's plan waits for.
+            if (fuse_order) {
+                const int slot = c->chain_n % 3;
+                HIPCHK(hipMemsetAsync(c->d_hp_bb_r[slot], 0xFF, 3 * sizeof(unsigned long long), st));
+                HIPCHK(hipMemsetAsync(c->d_hp_bb_r[slot] + 3, 0x00, 3 * sizeof(unsigned long long), st));
+                ep.bb_prev = c->d_hp_bb_r[c->view_chain[c->cur_view]]; ep.bb_out = c->d_hp_bb_r[slot]; ep.keys_out = c->d_hp_keys;
+            }
+            hipLaunchKernelGGL(k_eye_pass<0>, dim3(nblk(c->P, 256)), dim3(256), scene_lds(c), st, scene_of(c), ep, c->hp, c->view[nv], c->d_counters);
+        }
         HIPCHK(hipGetLastError());
     }
     if (c->gather_mode && c->n_own_pix > 0) {
@@ -890,11 +906,13 @@ static int eye_launch(sppm_ctx* c, int32_t pass, hipStream_t st)
         const int slot = c->chain_n % 3;
         c->chain_n++;
         c->view_chain[nv] = slot;
-        // bounding box seed: min slots all ones, max slots zero (ordered-int doubles); two memsets, nothing host-sourced
-        HIPCHK(hipMemsetAsync(c->d_hp_bb_r[slot], 0xFF, 3 * sizeof(unsigned long long), st));
-        HIPCHK(hipMemsetAsync(c->d_hp_bb_r[slot] + 3, 0x00, 3 * sizeof(unsigned long long), st));
-        hipLaunchKernelGGL(k_hp_bbox, dim3(std::min(nblk(c->n_own_pix, 256), 512)), dim3(256), 0, st, c->view[nv], c->d_own_pix, c->n_own_pix, c->d_hp_bb_r[slot]);
-        hipLaunchKernelGGL(k_hp_sortkeys, dim3(nblk(c->n_own_pix, 256)), dim3(256), 0, st, c->view[nv], c->d_own_pix, c->n_own_pix, c->d_hp_bb_r[slot], c->d_hp_keys);
+        if (!fuse_order) {
+            // bounding box seed: min slots all ones, max slots zero (ordered-int doubles); two memsets, nothing host-sourced
+            HIPCHK(hipMemsetAsync(c->d_hp_bb_r[slot], 0xFF, 3 * sizeof(unsigned long long), st));
+            HIPCHK(hipMemsetAsync(c->d_hp_bb_r[slot] + 3, 0x00, 3 * sizeof(unsigned long long), st));
+            hipLaunchKernelGGL(k_hp_bbox, dim3(std::min(nblk(c->n_own_pix, 256), 512)), dim3(256), 0, st, c->view[nv], c->d_own_pix, c->n_own_pix, c->d_hp_bb_r[slot]);
+            hipLaunchKernelGGL(k_hp_sortkeys, dim3(nblk(c->n_own_pix, 256)), dim3(256), 0, st, c->view[nv], c->d_own_pix, c->n_own_pix, c->d_hp_bb_r[slot], c->d_hp_keys);
+        }
         HIPCHK(hipGetLastError());
         HIPCHK(rocprim::radix_sort_pairs<HpSortConfig>(c->d_sort_tmp, c->sort_tmp_bytes, c->d_hp_keys, c->d_hp_keys_out, c->d_own_pix, c->d_order_r[slot],
                                          (size_t)c->n_own_pix, 0, MORTON_KEY_BITS, st));
