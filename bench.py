@@ -340,7 +340,7 @@ def run_render(args, rank, world, barrier, rule, table, torch, dist):
         all_reduce_sum(d)
     out = {"dt": float(tmax.item()), "c0": c0, "c1": c1, "sums": [float(x) for x in d.tolist()], "image": img, "describe": job.describe(),
            "replicated_trace": job.replicated_trace, "exchanged_bytes": job.exchanged_bytes,
-           "exchange_ms": [a.elapsed_time(b) for _, a, b in job.stage_events]}
+           "exchange_ms": [a.elapsed_time(b) for _, a, b in job.stage_events], "exchange_names": [n for n, _, _ in job.stage_events]}
     job.close()
     return out
 
@@ -411,8 +411,13 @@ def report(args, world, rule, r, table_name):
         out["rccl_ranks"] = dist.get_world_size()   # from the process group, not from the command line
         out["collective_backend"] = dist.get_backend()
         out["exchanged_bytes_per_pass_per_rank"] = r["exchanged_bytes"] / max(1, args.steps)
+        names = r.get("exchange_names") or []
+        per_slice = {}
+        for n, ms in zip(names, ex):
+            per_slice.setdefault(n, []).append(ms)
         out["stage_ms"] = {"trace_launch_avg": t_ns / 1e6 / t_launch, "exchange_avg": sum(ex) / len(ex) if ex else None, "gather_launch_avg": g_ns / 1e6 / g_launch,
-                           "note": "rank 0; trace overlaps the gather on its own streams; exchange = " + ("export + all-reduce + import of the deposits, per pass, on the context's stream" if rule == 1 else
+                           "exchange_avg_by_slice": {n: sum(v) / len(v) for n, v in sorted(per_slice.items())} if rule == 1 else None,
+                           "note": "rank 0; trace overlaps the gather on its own streams; exchange = " + ("per slice of the hitpoints (ShardedSppm.slices): from the end of the slice's export to the arrival of its sum on the context's stream -- the collectives of the slices run back to back on the process group's stream, so a later slice's time includes the earlier ones'; import and end of pass of a slice follow while the next collective runs" if rule == 1 else
                                     "counts + the record collective (all-to-all by destination, or all-gather), per batch, on a side stream beside the gather")}
     return out
 

@@ -227,6 +227,12 @@ int sppm_end_pass(sppm_ctx* ctx);
  * so the result does not depend on the number of ranks), the sum is imported, then sppm_end_pass.  update_rule 1. */
 int sppm_export_deposits(sppm_ctx* ctx, int64_t* d_out);
 int sppm_import_deposits(sppm_ctx* ctx, const int64_t* d_in);
+/* The same for the hitpoints [first, first + count) by image index: d_out / d_in are [4][count].  For a SLICED
+ * all-reduce: export every slice, start the collective of each on a side stream as soon as its export is done, and
+ * as each sum arrives import it and update that slice (sppm_end_pass_resolve_range) while the next collective is in
+ * flight.  Slices together must cover every hitpoint exactly once per pass. */
+int sppm_export_deposits_range(sppm_ctx* ctx, int64_t* d_out, int64_t first, int64_t count);
+int sppm_import_deposits_range(sppm_ctx* ctx, const int64_t* d_in, int64_t first, int64_t count);
 int sppm_fixed_point_scale(sppm_ctx* ctx, double* scale);
 
 /* Image assembly, src/sppm2.h:658-670: d_image[P][3] = ld/(pass+1) + flux/(pi r^2 (pass+1) photon_num). */
@@ -234,6 +240,10 @@ int sppm_resolve(sppm_ctx* ctx, int32_t pass, int64_t photon_num, double* d_imag
 /* sppm_end_pass then sppm_resolve in one call (src/stochastic_ppm.h:721-741 then :743-765; src/sppm2.h:658-670 under
  * rule 0).  Under the per-pass rule both run as ONE sweep over the hitpoints; results are those of the two calls. */
 int sppm_end_pass_resolve(sppm_ctx* ctx, int32_t pass, int64_t photon_num, double* d_image);
+/* update_rule 1, SPPM: the same for hitpoints [first, first + count) only.  d_image is the WHOLE image [P][3] (the rows
+ * of the range are written) or null for the update alone.  No counterpart in the reference (see
+ * sppm_export_deposits_range). */
+int sppm_end_pass_resolve_range(sppm_ctx* ctx, int32_t pass, int64_t photon_num, double* d_image, int64_t first, int64_t count);
 
 /* get_hdr_pixel on the device (src/hdr.h:37-45): d_rgbe[n][4]. */
 int sppm_hdr_pixels(sppm_ctx* ctx, const double* d_rgb, int64_t n, uint8_t* d_rgbe);

@@ -14,6 +14,7 @@ SYMBOLS = [
     "sppm_end_pass", "sppm_resolve", "sppm_end_pass_resolve", "sppm_hdr_pixels", "sppm_save_hdr_file", "sppm_save_ppm_file", "sppm_check",
     "sppm_download_hitpoints", "sppm_download_records", "sppm_owned_mask", "sppm_look_ahead", "sppm_look_ahead_rows", "sppm_rows_ready", "sppm_look_ahead_rows_to", "sppm_rows_ready_to", "sppm_download_tile_order", "sppm_accept_tap", "sppm_download_accepted", "sppm_counters",
     "sppm_set_timing", "sppm_measure_fma_peak", "sppm_intersect_static", "sppm_export_deposits", "sppm_import_deposits", "sppm_fixed_point_scale", "sppm_hitpoint_count", "sppm_download_hitpoint_pixels", "sppm_export_owned_state", "sppm_import_state",
+    "sppm_export_deposits_range", "sppm_import_deposits_range", "sppm_end_pass_resolve_range",
 ]
 
 
@@ -89,6 +90,9 @@ def lib():
     L.sppm_measure_fma_peak.argtypes = [vp, C.POINTER(C.c_double)]
     L.sppm_export_deposits.argtypes = [vp, vp]
     L.sppm_import_deposits.argtypes = [vp, vp]
+    L.sppm_export_deposits_range.argtypes = [vp, vp, i64, i64]
+    L.sppm_import_deposits_range.argtypes = [vp, vp, i64, i64]
+    L.sppm_end_pass_resolve_range.argtypes = [vp, i32, i64, vp, i64, i64]
     L.sppm_fixed_point_scale.argtypes = [vp, C.POINTER(C.c_double)]
     L.sppm_intersect_static.argtypes = [C.POINTER(SppmSphere), i32, vp, i64, vp, vp, vp, vp]
     for name in SYMBOLS:

@@ -732,13 +732,15 @@ __global__ void k_end_pass(HpArrays hp, DevScene sc, Own own, double alpha, doub
 
 // k_end_pass and k_resolve (sppm_image.hpp) in one sweep over the hitpoints: the image reads what the update has just
 // computed from registers instead of from memory in a second launch.  Same operations, same results.
+// Hitpoints [first, first + n) by image index (all of them, or one slice of the sliced all-reduce); image == nullptr:
+// the update alone.
 __global__ void k_end_pass_resolve(HpArrays hp, DevScene sc, Own own, double alpha, double fx_inv, int32_t* __restrict__ err, int pass, int64_t photon_num,
-                                   double* __restrict__ image)
+                                   double* __restrict__ image, int first, int n)
 {
     __builtin_amdgcn_s_setprio(3);  // (as k_deposit_plan: the next gather waits for it)
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int p = first + (int)(blockIdx.x * blockDim.x + threadIdx.x);
     const size_t P = (size_t)hp.P;
-    if (p >= hp.P) return;
+    if (p >= first + n || p >= hp.P) return;
     d3 c = mk(hp.ld[p], hp.ld[P + p], hp.ld[2 * P + p]) / (double)(pass + 1);
     if (hp.valid[p]) {
         d3 tau = mk(hp.tau[p], hp.tau[P + p], hp.tau[2 * P + p]);
@@ -762,5 +764,5 @@ __global__ void k_end_pass_resolve(HpArrays hp, DevScene sc, Own own, double alp
         }
         c = c + tau * (1.0 / (SPPM_PI * r2 * (double)((int64_t)(pass + 1) * photon_num)));
     }
-    image[3 * (size_t)p] = c.x; image[3 * (size_t)p + 1] = c.y; image[3 * (size_t)p + 2] = c.z;
+    if (image) { image[3 * (size_t)p] = c.x; image[3 * (size_t)p + 1] = c.y; image[3 * (size_t)p + 2] = c.z; }
 }

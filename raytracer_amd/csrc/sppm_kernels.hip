@@ -2024,7 +2024,24 @@ extern "C" int sppm_end_pass_resolve(sppm_ctx* c, int32_t pass, int64_t photon_n
         if (rc) return rc;
         return sppm_resolve(c, pass, photon_num, d_image);
     }
-    hipLaunchKernelGGL(k_end_pass_resolve, dim3(nblk(c->P, 256)), dim3(256), 0, c->stream, c->hp, scene_of(c), own_of(c), c->cfg.alpha, 1.0 / c->fx_scale, c->d_err, pass, photon_num, d_image);
+    hipLaunchKernelGGL(k_end_pass_resolve, dim3(nblk(c->P, 256)), dim3(256), 0, c->stream, c->hp, scene_of(c), own_of(c), c->cfg.alpha, 1.0 / c->fx_scale, c->d_err, pass, photon_num, d_image,
+                       0, (int)c->P);
+    HIPCHK(hipGetLastError());
+    return SPPM_OK;
+}
+
+// The same for hitpoints [first, first + count) only (update_rule 1, SPPM): one slice of a sliced all-reduce of the
+// deposits gets its update and its part of the image while the collective of the next slice is in flight.
+// d_image: the WHOLE image [P][3] (rows of the range are written), or null for the update alone.
+extern "C" int sppm_end_pass_resolve_range(sppm_ctx* c, int32_t pass, int64_t photon_num, double* d_image, int64_t first, int64_t count)
+{
+    if (!c || pass < 0 || photon_num < 1 || first < 0 || count < 0) return fail(SPPM_ERR_INVALID, "sppm_end_pass_resolve_range: bad argument");
+    CTX_DEVICE(c, "sppm_end_pass_resolve_range");
+    if (c->cfg.update_rule != 1 || c->algo == 1) return fail(SPPM_ERR_STATE, "sppm_end_pass_resolve_range: update_rule 1 (SPPM) only");
+    if (first + count > c->P) return fail(SPPM_ERR_INVALID, "sppm_end_pass_resolve_range: range exceeds the hitpoints");
+    if (count == 0) return SPPM_OK;
+    hipLaunchKernelGGL(k_end_pass_resolve, dim3(nblk(count, 256)), dim3(256), 0, c->stream, c->hp, scene_of(c), own_of(c), c->cfg.alpha, 1.0 / c->fx_scale, c->d_err, pass, photon_num, d_image,
+                       (int)first, (int)count);
     HIPCHK(hipGetLastError());
     return SPPM_OK;
 }
@@ -2261,6 +2278,26 @@ extern "C" int sppm_export_deposits(sppm_ctx* c, int64_t* d_out)
     CTX_DEVICE(c, "sppm_export_deposits");
     if (c->cfg.update_rule != 1) return fail(SPPM_ERR_STATE, "sppm_export_deposits: update_rule 1 only");
     if (c->P > 0) HIPCHK(hipMemcpyAsync(d_out, c->hp.dep, 4 * (size_t)c->P * sizeof(int64_t), hipMemcpyDeviceToDevice, c->stream));
+    return SPPM_OK;
+}
+
+// hitpoints [first, first + count) only: d_out / d_in are [4][count]
+extern "C" int sppm_export_deposits_range(sppm_ctx* c, int64_t* d_out, int64_t first, int64_t count)
+{
+    if (!c || (!d_out && count > 0) || first < 0 || count < 0) return fail(SPPM_ERR_INVALID, "sppm_export_deposits_range: bad argument");
+    CTX_DEVICE(c, "sppm_export_deposits_range");
+    if (c->cfg.update_rule != 1) return fail(SPPM_ERR_STATE, "sppm_export_deposits_range: update_rule 1 only");
+    if (first + count > c->P) return fail(SPPM_ERR_INVALID, "sppm_export_deposits_range: range exceeds the hitpoints");
+    if (count > 0) HIPCHK(hipMemcpy2DAsync(d_out, (size_t)count * 8, c->hp.dep + first, (size_t)c->P * 8, (size_t)count * 8, 4, hipMemcpyDeviceToDevice, c->stream));
+    return SPPM_OK;
+}
+extern "C" int sppm_import_deposits_range(sppm_ctx* c, const int64_t* d_in, int64_t first, int64_t count)
+{
+    if (!c || (!d_in && count > 0) || first < 0 || count < 0) return fail(SPPM_ERR_INVALID, "sppm_import_deposits_range: bad argument");
+    CTX_DEVICE(c, "sppm_import_deposits_range");
+    if (c->cfg.update_rule != 1) return fail(SPPM_ERR_STATE, "sppm_import_deposits_range: update_rule 1 only");
+    if (first + count > c->P) return fail(SPPM_ERR_INVALID, "sppm_import_deposits_range: range exceeds the hitpoints");
+    if (count > 0) HIPCHK(hipMemcpy2DAsync(c->hp.dep + first, (size_t)c->P * 8, d_in, (size_t)count * 8, (size_t)count * 8, 4, hipMemcpyDeviceToDevice, c->stream));
     return SPPM_OK;
 }
 

@@ -44,10 +44,12 @@ class ShardedSppm:
     traces photons [rank*M/world, (rank+1)*M/world) of the pass (streams keyed by global photon index) and deposits
     them into 64-bit fixed-point accumulators; ONE all-reduce (sum) of the accumulators per pass (4 x 8 bytes per
     hitpoint: 66 MB at 1080p), then every rank applies the same end-of-pass update.  Integer sums are exact, so the
-    result is bit-identical for every world size."""
+    result is bit-identical for every world size.  The all-reduce is issued in `slices` parts (ranges of the image
+    index): every slice's collective starts as soon as its export is done, and a slice is imported and updated
+    (sppm_end_pass_resolve_range) while the collectives of the later slices are still in flight."""
 
     def __init__(self, width, height, photons_per_rank, rank=0, world=1, exchange=None, ownership=1,
-                 spheres=scene.CORNELL_SPHERES, photons_total=None, rule=0, **cfg_kw):
+                 spheres=scene.CORNELL_SPHERES, photons_total=None, rule=0, slices=4, **cfg_kw):
         if rule not in (0, 1):
             raise ValueError("rule must be 0 (per-photon update, sppm2.h) or 1 (per-pass update, stochastic_ppm.h)")
         if exchange is None:
@@ -63,6 +65,7 @@ class ShardedSppm:
         self.M_rank = photons_per_rank
         self.M = photons_per_rank * world
         self.rule = rule
+        self.slices = max(1, int(slices))
         self.exchange = exchange if (world > 1 or rule == 1) else "replicate"
         self.replicated_trace = self.exchange == "replicate"
         self.ownership = ownership
@@ -86,7 +89,7 @@ class ShardedSppm:
         if self.world == 1:
             return "1 GPU"
         if self.rule == 1:
-            return f"{self.world} ranks: photons sharded by global index, hitpoints replicated, one all-reduce of the fixed-point deposits per pass"
+            return f"{self.world} ranks: photons sharded by global index, hitpoints replicated, one all-reduce of the fixed-point deposits per pass (in {self.slices} slices)"
         how = "ranges of the hitpoints' Morton order" if self.ownership == 1 else "8x8 hitpoint tiles dealt round-robin"
         return f"{self.world} ranks: hitpoints by {how}, photon records by {self.exchange}"
 
@@ -96,7 +99,8 @@ class ShardedSppm:
         ctx.eye_pass(i)
         if self.rule == 1:
             ctx.photon_pass(i, self.M_rank, first=self.rank * self.M_rank)
-            self._allreduce_deposits()
+            if self.world > 1 and ctx.n_hitpoints >= self.slices:
+                return self._allreduce_and_end_pass(i, resolve)
         elif self.replicated_trace:
             ctx.photon_pass(i, self.M)
         else:
@@ -107,24 +111,43 @@ class ShardedSppm:
             ctx.end_pass()
         return self.image
 
-    # ---- per-pass rule: one all-reduce of the deposits ---------------------------------------------------
-    def _allreduce_deposits(self):
-        """sum the ranks' accumulators [4][P] (int64) in place and hand the sum back to the context; the next pass's
-        tracing and eye pass already run on the context's look-ahead streams meanwhile"""
-        if self.world == 1:
-            return
+    # ---- per-pass rule: one all-reduce of the deposits, in slices -------------------------------------------
+    def _allreduce_and_end_pass(self, i, resolve):
+        """Sum the ranks' accumulators [4][P] (int64) and apply the end of the pass, slice by slice: export every slice
+        and start its collective at once (RCCL: asynchronously, on the process group's stream behind the export); then,
+        in order, wait for a slice's sum, import it and update its hitpoints (+ their part of the image) while the later
+        collectives are still running.  The next pass's tracing and eye pass already run on the context's look-ahead
+        streams meanwhile.  gloo (tests): the same calls, each collective synchronous through pinned host memory."""
         import torch
-        ev = None
-        if self.time_stages:
-            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-            ev[0].record()
-        self._dep = self.ctx.export_deposits(self._dep)
-        all_reduce_sum(self._dep)
-        self.ctx.import_deposits(self._dep)
-        self.exchanged_bytes += self._dep.numel() * 8
-        if ev:
-            ev[1].record()
-            self.stage_events.append(("exchange",) + ev)
+        import torch.distributed as dist
+        ctx, S, P = self.ctx, self.slices, self.ctx.n_hitpoints
+        bounds = [P * s // S for s in range(S + 1)]
+        if self._dep is None:
+            self._dep = [torch.empty((4, bounds[s + 1] - bounds[s]), dtype=torch.int64, device=ctx.device) for s in range(S)]
+        image = torch.empty((P, 3), dtype=torch.float64, device=ctx.device) if resolve else None
+        staged = _host_staged(self._dep[0])
+        works, evs = [], []
+        for s in range(S):
+            ctx.export_deposits_range(self._dep[s], bounds[s], bounds[s + 1] - bounds[s])
+            if self.time_stages:
+                e = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                e[0].record()
+                evs.append(e)
+            works.append(None if staged else dist.all_reduce(self._dep[s], op=dist.ReduceOp.SUM, async_op=True))
+        for s in range(S):
+            if staged:
+                all_reduce_sum(self._dep[s])
+            else:
+                works[s].wait()   # the current stream waits for the collective; the host does not
+            if self.time_stages:
+                evs[s][1].record()
+                self.stage_events.append((f"exchange_slice{s}",) + evs[s])
+            ctx.import_deposits_range(self._dep[s], bounds[s], bounds[s + 1] - bounds[s])
+            ctx.end_pass_resolve_range(i, self.M, image, bounds[s], bounds[s + 1] - bounds[s])
+            self.exchanged_bytes += self._dep[s].numel() * 8
+        if resolve:
+            self.image = image
+        return self.image
 
     def _stage_begin(self):
         """events around an exchange on the current stream (time_stages): device time of the collective as enqueued"""

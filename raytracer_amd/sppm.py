@@ -201,6 +201,20 @@ class SppmContext:
         capi.check(self.L.sppm_import_deposits(self.h, dep.data_ptr()))
         self._keep_dep = dep  # the copy is asynchronous
 
+    def export_deposits_range(self, out, first, count):
+        """the deposits of hitpoints [first, first + count) into out[4][count] (int64, contiguous)"""
+        assert out.dtype == self.torch.int64 and tuple(out.shape) == (4, count) and out.is_contiguous()
+        capi.check(self.L.sppm_export_deposits_range(self.h, out.data_ptr(), first, count))
+        return out
+
+    def import_deposits_range(self, dep, first, count):
+        assert dep.dtype == self.torch.int64 and tuple(dep.shape) == (4, count) and dep.is_contiguous() and dep.device == self.device
+        capi.check(self.L.sppm_import_deposits_range(self.h, dep.data_ptr(), first, count))
+
+    def end_pass_resolve_range(self, i, photon_num, image, first, count):
+        """end of the pass for hitpoints [first, first + count); image: the whole [P][3] tensor or None"""
+        capi.check(self.L.sppm_end_pass_resolve_range(self.h, i, photon_num, image.data_ptr() if image is not None else None, first, count))
+
     def fixed_point_scale(self):
         v = C.c_double()
         capi.check(self.L.sppm_fixed_point_scale(self.h, C.byref(v)))

@@ -169,3 +169,39 @@ def test_fused_end_of_pass_equals_the_two_calls(rule):
             _same(sb[k], sa[k], f"pass {i} state {k}")
     a.check(); b.check()
     a.close(); b.close()
+
+
+def test_end_of_pass_by_slices_equals_the_whole():
+    """sppm_export_deposits_range / sppm_import_deposits_range / sppm_end_pass_resolve_range over ragged slices of the
+    image index (what the sliced all-reduce of ShardedSppm does per pass) == the whole-array calls: the exported slices
+    are the whole export's columns, state and image bit for bit, pass after pass; a range past the end is refused."""
+    import torch
+    W, H, M = 96, 64, 20000
+    P = W * H
+    a = sppm.SppmContext(sppm.make_config(W, H, photons_per_pass=M, update_rule=1))
+    b = sppm.SppmContext(sppm.make_config(W, H, photons_per_pass=M, update_rule=1))
+    bounds = [0, 1, 1000, 1000, 4097, P]   # a single hitpoint, an empty slice, ragged ones
+    for i in range(3):
+        a.eye_pass(i); a.photon_pass(i, M); ia = a.end_pass_resolve(i, M).cpu().numpy()
+        b.eye_pass(i); b.photon_pass(i, M)
+        whole = b.export_deposits().clone()
+        img = torch.empty((P, 3), dtype=torch.float64, device=b.device)
+        parts = []
+        for lo, hi in zip(bounds[:-1], bounds[1:]):
+            d = torch.empty((4, hi - lo), dtype=torch.int64, device=b.device)
+            b.export_deposits_range(d, lo, hi - lo)
+            parts.append(d)
+        assert torch.equal(torch.cat(parts, dim=1), whole), "the slices are the whole export's columns"
+        for (lo, hi), d in zip(zip(bounds[:-1], bounds[1:]), parts):
+            b.import_deposits_range(d * 2, lo, hi - lo)      # (something else than what is there: the import must land)
+            b.import_deposits_range(d, lo, hi - lo)
+            b.end_pass_resolve_range(i, M, img, lo, hi - lo)
+        _same(img.cpu().numpy(), ia, f"pass {i} image")
+        sa, sb = a.hitpoints(), b.hitpoints()
+        for k in ("r2", "flux", "n"):
+            _same(sb[k], sa[k], f"pass {i} state {k}")
+        assert int(b.export_deposits().abs().sum().item()) == 0, "the end of the pass clears the deposits"
+    with pytest.raises(Exception):
+        b.export_deposits_range(torch.empty((4, 2), dtype=torch.int64, device=b.device), P - 1, 2)
+    a.check(); b.check()
+    a.close(); b.close()
