@@ -42,6 +42,24 @@ def main():
         parallel.all_reduce_sum(dep)
         torch.cuda.synchronize()
         assert table == [[7]] and torch.equal(dst, src) and torch.equal(dep, want)
+        # the sliced all-reduce of the per-pass rule on RCCL: asynchronous collectives behind each slice's export, the
+        # context's stream waiting for each sum (a world of one still runs every call) == the plain passes, bit for bit
+        from raytracer_amd import sppm
+        job = ShardedSppm(W, H, photons_per_rank=M_rank, rank=0, world=1, rule=1, slices=3)
+        plain = sppm.SppmContext(sppm.make_config(W, H, photons_per_pass=M_rank, update_rule=1))
+        job.time_stages = True
+        for i in range(passes):
+            job.ctx.eye_pass(i); job.ctx.photon_pass(i, M_rank)
+            img = job._allreduce_and_end_pass(i, True)
+            plain.eye_pass(i); plain.photon_pass(i, M_rank)
+            ref = plain.end_pass_resolve(i, M_rank)
+            assert torch.equal(img, ref), f"pass {i}: image of the sliced flow"
+        job.ctx.check(); plain.check()
+        a, b = job.ctx.hitpoints(), plain.hitpoints()
+        for k in ("n", "r2", "flux"):
+            assert (np.ascontiguousarray(a[k]).view(np.uint8) == np.ascontiguousarray(b[k]).view(np.uint8)).all(), k
+        assert len(job.stage_events) == 3 * passes and all(e0.elapsed_time(e1) >= 0.0 for _, e0, e1 in job.stage_events)
+        job.close(); plain.close()
         dist.destroy_process_group()
         return
     dist.init_process_group("gloo", rank=rank, world_size=world)
