@@ -269,7 +269,7 @@ __global__ void __launch_bounds__(256) k_items_place(const unsigned long long* _
 #define DEP_ATTR __attribute__((amdgpu_waves_per_eu(DEP_WAVES, DEP_WAVES)))
 #define DEP_FLUSH_ROWS 2048  // staged rows after which the double sums move to the 64-bit integers (2048 x 2^41 = 2^52)
 #ifndef DEP_NEAR_MAX
-#define DEP_NEAR_MAX 1e-4  // third class of staged records: largest G as a share of the cluster's largest squared radius (k_deposit_tiles)
+#define DEP_NEAR_MAX 1e-4
 #endif
 #define DEP_ROWS 64  // staged records per wavefront: one group of candidates at a time, processed while the next group's loads are in flight
 // VETO: the reference's K cap is enforced (sppm_cap.hpp): a pair the capped kd search dropped is in tp.veto and is not
@@ -325,6 +325,8 @@ __global__ void __launch_bounds__(256) DEP_ATTR k_deposit_tiles(HpArrays hp, Rec
     const double rmax2 = pin_scalar_d(R.rmax * R.rmax);  // (pin_scalar_d: wave-uniform values kept in scalar registers, see the cluster bounds below)
     const int kx = R.cx1 - R.cx0 + 1, ky = R.cy1 - R.cy0 + 1, kz = R.cz1 - R.cz0 + 1;
     const int Ktot = kx * ky * kz;
+    // (a row of kx cells along x is one run of consecutive records: the region is walked row by row, 64 rows at a time)
+    const int Krows = ky * kz;
     d3 hn[DEP_H];
 #pragma unroll
     for (int h = 0; h < DEP_H; h++) hn[h] = inc[h] ? mk(hp.nrm[t.p[h]], hp.nrm[P + t.p[h]], hp.nrm[2 * P + t.p[h]]) : mk(0, 0, 0);
@@ -335,16 +337,14 @@ __global__ void __launch_bounds__(256) DEP_ATTR k_deposit_tiles(HpArrays hp, Rec
     st_setup += ts_setup - ts_item;
     if (cn > 1) {
         unsigned int T = 0;
-        for (int qbase = 0; qbase < Ktot; qbase += 64) {
+        for (int qbase = 0; qbase < Krows; qbase += 64) {
             const int qi = qbase + lane;
             uint32_t cnt = 0;
-            if (qi < Ktot) {
-                const int ix = R.cx0 + qi % kx, iy = R.cy0 + (qi / kx) % ky, iz = R.cz0 + qi / (kx * ky);
-                const uint32_t b = (uint32_t)((iz * tp.g.ny + iy) * tp.g.nx + ix);
-                cnt = cell_start[b + 1] - cell_start[b];
+            if (qi < Krows) {
+                const uint32_t b = (uint32_t)(((R.cz0 + qi / ky) * tp.g.ny + R.cy0 + qi % ky) * tp.g.nx + R.cx0);
+                cnt = cell_start[b + kx] - cell_start[b];
             }
-            for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
-            T += (unsigned int)__builtin_amdgcn_readfirstlane((int)cnt);
+            T += (unsigned int)__builtin_amdgcn_readlane((int)wave_incl_scan_u32(cnt), 63);
         }
         v_lo = (unsigned int)((unsigned long long)T * (unsigned int)cj / (unsigned int)cn);
         v_hi = (unsigned int)((unsigned long long)T * (unsigned int)(cj + 1) / (unsigned int)cn);
@@ -430,12 +430,12 @@ __global__ void __launch_bounds__(256) DEP_ATTR k_deposit_tiles(HpArrays hp, Rec
     st_count += DSTAMP() - ts_setup;
     unsigned int c_sel = 0, c_round = 0;
     unsigned long long c_pairs = 0;
-    unsigned long long d_easy = 0, d_full = 0, d_near = 0, d_near_slow = 0;  // diagnostic build: staged records by class
+    unsigned long long d_easy = 0, d_full = 0, d_near = 0, d_near_slow = 0, d_win = 0, d_grp = 0, d_load = 0;  // diagnostic build: staged records by class
     int sel_n = 0, n_easy = 0, n_near = 0, n_full = 0;
     // iterator over the list in groups of 64 entries
     int qbase = -64;
     unsigned int voff = 0, cbase = 0, i_end = 0;
-    uint32_t g_cs = 0, g_pre = 0;
+    uint32_t g_d = 0, g_pre = 0;
     bool pend = false, p_has = false;          // a group whose loads are in flight
     uint32_t p_r = 0;
     double p0 = 0, p1 = 0, p2 = 0, p3 = 0, p4 = 0, p5 = 0, p6 = 0, p7 = 0, p8 = 0;
@@ -445,38 +445,40 @@ __global__ void __launch_bounds__(256) DEP_ATTR k_deposit_tiles(HpArrays hp, Rec
         pend = true;                                                                                                   \
         while (cbase >= i_end) {                                                                                       \
             qbase += 64;                                                                                               \
-            if (qbase >= Ktot || voff >= v_hi) { pend = false; break; }                                                \
+            if (STAMPS) d_win++;                                                                                       \
+            if (qbase >= Krows || voff >= v_hi) { pend = false; break; }                                               \
             const int qi = qbase + lane;                                                                               \
-            uint32_t cnt = 0;                                                                                          \
-            g_cs = 0;                                                                                                  \
-            if (qi < Ktot) {                                                                                           \
-                const int ix = R.cx0 + qi % kx, iy = R.cy0 + (qi / kx) % ky, iz = R.cz0 + qi / (kx * ky);             \
-                const uint32_t b = (uint32_t)((iz * tp.g.ny + iy) * tp.g.nx + ix);                                     \
-                g_cs = cell_start[b];                                                                                  \
-                cnt = cell_start[b + 1] - g_cs;                                                                        \
+            uint32_t cnt = 0, cs = 0;                                                                                  \
+            if (qi < Krows) {                                                                                          \
+                const uint32_t b = (uint32_t)(((R.cz0 + qi / ky) * tp.g.ny + R.cy0 + qi % ky) * tp.g.nx + R.cx0);      \
+                cs = cell_start[b];                                                                                    \
+                cnt = cell_start[b + kx] - cs;                                                                         \
             }                                                                                                          \
-            uint32_t incl = cnt;                                                                                       \
-            for (int off = 1; off < 64; off <<= 1) { const uint32_t yy = __shfl_up(incl, off); if (lane >= off) incl += yy; } \
+            const uint32_t incl = wave_incl_scan_u32(cnt);                                                             \
             g_pre = incl - cnt;                                                                                        \
-            const unsigned int tot = (unsigned int)__builtin_amdgcn_readlane((int)incl, 63);                          \
+            g_d = cs - g_pre; /* list entry i of a row lies at g_d + i */                                              \
+            const unsigned int tot = (unsigned int)__builtin_amdgcn_readlane((int)incl, 63);                           \
             const unsigned int g_lo = voff, g_hi = voff + tot;                                                         \
             voff = g_hi;                                                                                               \
             cbase = 0; i_end = 0;                                                                                      \
             if (g_hi <= v_lo || g_lo >= v_hi) continue;                                                                \
-            cbase = (v_lo > g_lo ? v_lo : g_lo) - g_lo; i_end = (v_hi < g_hi ? v_hi : g_hi) - g_lo;                     \
+            cbase = (v_lo > g_lo ? v_lo : g_lo) - g_lo; i_end = (v_hi < g_hi ? v_hi : g_hi) - g_lo;                    \
         }                                                                                                              \
         if (pend) {                                                                                                    \
             const unsigned int i = cbase + (unsigned int)lane;                                                         \
             p_has = i < i_end;                                                                                         \
-            int j = 0; /* the cell lane that owns list entry i: the largest j with pre_j <= i */                       \
-            for (int step = 32; step >= 1; step >>= 1) {                                                               \
-                const int cand = j + step;                                                                             \
-                const uint32_t pv = __shfl(g_pre, cand & 63);                                                          \
-                if (cand < 64 && pv <= i) j = cand;                                                                    \
+            if (STAMPS) { d_grp++; d_load += (unsigned long long)__popcll(ballot64(p_has)); }                          \
+            {                                                                                                          \
+                int j = 0; /* the row lane that owns list entry i: the largest j with pre_j <= i */                    \
+                for (int step = 32; step >= 1; step >>= 1) {                                                           \
+                    const int cand = j + step;                                                                         \
+                    const uint32_t pv = __shfl(g_pre, cand & 63);                                                      \
+                    if (cand < 64 && pv <= i) j = cand;                                                                \
+                }                                                                                                      \
+                p_r = __shfl(g_d, j) + i;                                                                              \
             }                                                                                                          \
-            p_r = __shfl(g_cs, j) + (i - __shfl(g_pre, j));                                                            \
             if (p_has) {                                                                                               \
-                const double2* rp = (const double2*)(rec.f + (size_t)REC_ROW * p_r);  /* one row: sppm_records.hpp */   \
+                const double2* rp = (const double2*)(rec.f + (size_t)REC_ROW * p_r);  /* one row: sppm_records.hpp */  \
                 const double2 ra = rp[0], rb = rp[1], rc = rp[2], rd = rp[3], re = rp[4];                              \
                 p0 = ra.x; p1 = ra.y; p2 = rb.x; p3 = rb.y; p4 = rc.x; p5 = rc.y; p6 = rd.x; p7 = rd.y; p8 = re.x;     \
                 if (KEYS) p_key = (unsigned long long)__double_as_longlong(re.y);                                      \
@@ -693,7 +695,7 @@ __global__ void __launch_bounds__(256) DEP_ATTR k_deposit_tiles(HpArrays hp, Rec
         if (c_sel) atomicAdd(&counters[5], (unsigned long long)c_sel);
         if (c_round) atomicAdd(&counters[6], (unsigned long long)c_round);
         atomicAdd(&counters[7], 1ull);
-        if (STAMPS) { atomicAdd(&counters[22], d_easy); atomicAdd(&counters[15], d_full); atomicAdd(&counters[8], d_near); atomicAdd(&counters[9], d_near_slow); }
+        if (STAMPS) { atomicAdd(&counters[22], d_easy); atomicAdd(&counters[15], d_full); atomicAdd(&counters[8], d_near); atomicAdd(&counters[9], d_near_slow); atomicAdd(&counters[10], d_win); atomicAdd(&counters[11], d_grp); atomicAdd(&counters[12], d_load); atomicAdd(&counters[13], (unsigned long long)Ktot); }
     }
     __builtin_amdgcn_wave_barrier();
     st_flush += DSTAMP() - tf0;

@@ -156,6 +156,20 @@ __device__ __forceinline__ double wave_min_d(double v)
     return rl_d(v, 63);
 }
 
+// inclusive prefix sum over the wavefront, the same way: Hillis-Steele inside each row of 16 lanes (a lane whose source
+// lies outside its row adds 0), then lane 15 of rows 0 and 2 into rows 1 and 3, then lane 31 into rows 2 and 3.
+// Every lane must be active.
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);
+    return v;
+}
+
 // the same by LDS permutes (the ordered gather keeps these: with the DPP forms its register allocation came out worse
 // and the kernel 7 % slower)
 __device__ __forceinline__ double wave_max_perm_d(double v)

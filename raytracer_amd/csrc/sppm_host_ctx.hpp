@@ -50,7 +50,8 @@ struct sppm_ctx {
     double fx_scale;          // per-pass rule: fixed point of the deposits (sppm_deposit.hpp), a power of two
     double cell_factor_dep;   // per-pass rule: cell size of the record grid as a share of the median tile extent
     int64_t dep_chunk;        // per-pass rule: records per work item
-    double dep_light, dep_heavy;  // per-pass rule: pairs per photon at which the deposit kernel runs on 576 / 768 workgroups (deposit_tiles)
+    double dep_light, dep_heavy;  // per-pass rule: pairs per photon at which the deposit kernel runs on dep_min / 768 workgroups (deposit_tiles)
+    int dep_min;
     int order_valid;
     sppm_sphere* d_spheres; int ns;
     DevScene dscene;   // what the kernels get: the table, and for large scenes the grid over the small spheres

@@ -365,15 +365,16 @@ static int deposit_tiles(sppm_ctx* c)
     c->stat_w ^= 1; c->stat_n++;
     c->est_valid = 0;  // (the estimates of the ordered gather's plan are not made here)
     // Persistent workgroups: three of the four wavefront slots of every SIMD while the deposit is the pass's long pole
-    // (the first passes of a render: ~2800 pairs examined per photon at 1080p), down to 2.25 of them once it is not
+    // (the first passes of a render: ~2800 pairs examined per photon at 1080p), down to two of them once it is not
     // (~1600 pairs per photon from pass ~100 on): what runs beside the kernel -- the eye pass of the next pass with its
-    // sort, the tracer, the binning -- gets one workgroup slot per CU next to three resident deposit workgroups, and late
-    // in a render the next deposit waits for that eye pass, not for this kernel.  Measured (photons/s at 20 / 256
-    // passes): 768 workgroups 267M / 305M, 704 266M / 310M, 640 260M / 313M, 576 249M / 317M, 512 237M / 313M.
+    // sort, the tracer, the binning -- gets the other slots, and late in a render the next deposit waits for that eye
+    // pass, not for this kernel.  Measured with fixed counts (photons/s at 20 / 256 passes, before the walk by rows of
+    // cells): 768 workgroups 267M / 305M, 704 266M / 310M, 640 260M / 313M, 576 249M / 317M, 512 237M / 313M; with the
+    // walk by rows the kernel is shorter and the late optimum moved from 576 to 512.
     int dep_blocks = 256 * 3;
     if (c->pairs_per_photon > 0.0) {
         const double t = std::min(1.0, std::max(0.0, (c->pairs_per_photon - c->dep_light) / (c->dep_heavy - c->dep_light)));
-        dep_blocks = 576 + 64 * (int)std::lround(3.0 * t);
+        dep_blocks = c->dep_min + 64 * (int)std::lround((768 - c->dep_min) / 64.0 * t);
     }
     const int blocks = std::max(1, std::min(nblk(n_dep_tiles, 4) * 4, (int)env_i64("SPPM_DEP_BLOCKS", dep_blocks)));
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -384,7 +385,7 @@ static int deposit_tiles(sppm_ctx* c)
     const bool dep_wg = env_i64("SPPM_DEP_WG", 0) != 0 && DEP_H == 1;
     if (stamps) {
         HIPCHK(hipMemsetAsync(c->d_counters + 15, 0, 9 * sizeof(unsigned long long), st));
-        HIPCHK(hipMemsetAsync(c->d_counters + 8, 0, 2 * sizeof(unsigned long long), st));
+        HIPCHK(hipMemsetAsync(c->d_counters + 8, 0, 6 * sizeof(unsigned long long), st));
         hipLaunchKernelGGL((k_deposit_tiles<false, true>), dim3(blocks), dim3(256), 0, st, c->hp, BS.rec_s, BS.cell_start, tp, c->d_items, c->d_item_q, c->d_counters, c->d_err);
         unsigned long long t[24];
         HIPCHK(hipMemcpyAsync(t, c->d_counters, sizeof t, hipMemcpyDeviceToHost, st));
@@ -392,6 +393,8 @@ static int deposit_tiles(sppm_ctx* c)
         const double tot = (double)(t[16] + t[17] + t[18] + t[19] + t[20] + t[21]);
         fprintf(stderr, "[sppm] deposit: items %llu, shares of wave cycles: setup %.1f%% count %.1f%% issue %.1f%% append %.1f%% (of it waiting for the group's loads %.1f%%) process %.1f%% flush %.1f%%; grid %dx%dx%d\n", t[7],
                 100.0 * t[16] / tot, 100.0 * t[17] / tot, 100.0 * t[18] / tot, 100.0 * t[19] / tot, 100.0 * t[23] / tot, 100.0 * t[20] / tot, 100.0 * t[21] / tot, g.nx, g.ny, g.nz);
+        fprintf(stderr, "[sppm]   lanes in their cluster per staged row (cumulative): %.1f of 64; staged rows per item %.0f\n", (double)t[3] / std::max(1.0, (double)t[5]), (double)t[5] / std::max(1.0, (double)t[7]));
+        fprintf(stderr, "[sppm]   this launch: windows of 64 cells %llu, groups loaded %llu, records loaded %llu (%.1f per group), cells in the regions %llu\n", t[10], t[11], t[12], (double)t[12] / std::max(1.0, (double)t[11]), t[13]);
         fprintf(stderr, "[sppm]   staged records by class: distance test only %llu, distance + pair flatness bound %llu (groups that needed the exact expressions: %llu), full test %llu (records rejected for the whole cluster are not staged)\n", t[22], t[8], t[9], t[15]);
     } else if (c->veto_dev.n != nullptr) {  // the K cap acts on this batch: the pairs it dropped are withheld
         if (c->tap_cap > 0) hipLaunchKernelGGL((k_deposit_tiles<true, false, true>), dim3(blocks), dim3(256), 0, st, c->hp, BS.rec_s, BS.cell_start, tp, c->d_items, c->d_item_q, c->d_counters, c->d_err);
