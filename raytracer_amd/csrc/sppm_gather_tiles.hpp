@@ -449,7 +449,7 @@ __global__ void __launch_bounds__(256) GATHER_WAVES_ATTR k_gather_tiles(HpArrays
         const int cz0 = __builtin_amdgcn_readfirstlane(grid_coord(lz, tp.g.oz, tp.g.inv_c, tp.g.nz));
         const int cz1 = __builtin_amdgcn_readfirstlane(grid_coord(hz, tp.g.oz, tp.g.inv_c, tp.g.nz));
         const int kx = cx1 - cx0 + 1, ky = cy1 - cy0 + 1, kz = cz1 - cz0 + 1;
-        const int Ktot = kx * ky * kz;
+        const int Krows = ky * kz;
         const uint32_t slab_base = (uint32_t)s * (uint32_t)tp.g.ncells;
         const unsigned long long kend = (unsigned long long)(tp.g.first + (int64_t)(s + 1) * tp.g.B) << KEY_SHIFT;
         unsigned long long klo = (unsigned long long)(tp.g.first + (int64_t)s * tp.g.B) << KEY_SHIFT;
@@ -459,17 +459,16 @@ __global__ void __launch_bounds__(256) GATHER_WAVES_ATTR k_gather_tiles(HpArrays
             int sel_n = 0;
             bool overflow = false;
             const unsigned long long ts0 = TSTAMP();
-            for (int qbase = 0; qbase < Ktot && !overflow; qbase += 64) {
+            // (a row of kx cells along x is one run of consecutive records: the region is walked row by row, 64 rows at a time)
+            for (int qbase = 0; qbase < Krows && !overflow; qbase += 64) {
                 const int q = qbase + lane;
                 uint32_t cs = 0, cn = 0;
-                if (q < Ktot) {
-                    const int ix = cx0 + q % kx, iy = cy0 + (q / kx) % ky, iz = cz0 + q / (kx * ky);
-                    const uint32_t b = slab_base + (uint32_t)((iz * tp.g.ny + iy) * tp.g.nx + ix);
+                if (q < Krows) {
+                    const uint32_t b = slab_base + (uint32_t)(((cz0 + q / ky) * tp.g.ny + cy0 + q % ky) * tp.g.nx + cx0);
                     cs = cell_start[b];
-                    cn = cell_start[b + 1] - cs;
+                    cn = cell_start[b + kx] - cs;
                 }
-                uint32_t incl = cn;  // inclusive scan over the wave
-                for (int off = 1; off < 64; off <<= 1) { const uint32_t y = __shfl_up(incl, off); if (lane >= off) incl += y; }
+                const uint32_t incl = wave_incl_scan_u32(cn);
                 const uint32_t pre = incl - cn;
                 const int tot = __builtin_amdgcn_readlane((int)incl, 63);
                 for (int cbase = 0; cbase < tot && !overflow; cbase += 64) {
@@ -486,14 +485,13 @@ __global__ void __launch_bounds__(256) GATHER_WAVES_ATTR k_gather_tiles(HpArrays
                     bool in = false;
                     unsigned long long key = 0;
                     if (has) {
+                        // (key and position are read together: a slab's cells hold that slab's records, so the key test
+                        // nearly always passes, and a second, dependent round trip to memory per group costs more than the bytes)
                         const double2* rp = (const double2*)(rec.f + (size_t)REC_ROW * r);  // one row: sppm_records.hpp
+                        const double2 ra = rp[0];
+                        const double qz = rp[1].x;
                         key = (unsigned long long)__double_as_longlong(rp[4].y);
-                        in = key >= klo && key < khi;
-                        if (in) {
-                            const double2 ra = rp[0];
-                            const double qx = ra.x, qy = ra.y, qz = rp[1].x;
-                            in = qx >= lx && qx <= hx && qy >= ly && qy <= hy && qz >= lz && qz <= hz;
-                        }
+                        in = key >= klo && key < khi && ra.x >= lx && ra.x <= hx && ra.y >= ly && ra.y <= hy && qz >= lz && qz <= hz;
                     }
                     c_cand += (unsigned int)__popcll(__ballot(has));
                     const unsigned long long m = __ballot(in);
