@@ -269,7 +269,13 @@ __global__ void __launch_bounds__(256) k_items_place(const unsigned long long* _
 #define DEP_ATTR __attribute__((amdgpu_waves_per_eu(DEP_WAVES, DEP_WAVES)))
 #define DEP_FLUSH_ROWS 2048  // staged rows after which the double sums move to the 64-bit integers (2048 x 2^41 = 2^52)
 #ifndef DEP_NEAR_MAX
+typedef double v2d __attribute__((ext_vector_type(2)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
 #define DEP_NEAR_MAX 1e-4
+#ifndef DEP_E32_SCALE
+#define DEP_E32_SCALE 1.0  // (a build with 1e4 here sends every hundredth pair through the exact fallback: how that path was validated)
+#endif
 #endif
 #define DEP_ROWS 64  // staged records per wavefront: one group of candidates at a time, processed while the next group's loads are in flight
 // VETO: the reference's K cap is enforced (sppm_cap.hpp): a pair the capped kd search dropped is in tp.veto and is not
@@ -281,9 +287,11 @@ __global__ void __launch_bounds__(256) DEP_ATTR k_deposit_tiles(HpArrays hp, Rec
 {
     constexpr bool KEYS = TAP || VETO;  // the staged rows carry the record's key
     constexpr int ROW = KEYS ? 11 : 10;
+    constexpr bool F32 = !VETO && DEP_H == 1;  // the distance-only rows in single precision (see the easy loop)
     // a staged record of the full test: position, geometric normal, fixed-point flux (integer-valued doubles); of the distance-only
     // test: position about the cluster's centre, its square, flux, position; [ROW - 1: key bits]
-    __shared__ double s_row[4][DEP_ROWS][ROW];
+    __shared__ __align__(16) double s_row[4][DEP_ROWS][ROW];
+    __shared__ uint32_t s_idx[4][DEP_ROWS];  // (single-precision rows: the record's place, for the pairs decided from the record itself)
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int P = hp.P;
     const double thr = tp.gather_r2 * 0.01;
@@ -412,12 +420,24 @@ __global__ void __launch_bounds__(256) DEP_ATTR k_deposit_tiles(HpArrays hp, Rec
     const double m2x = -2.0 * hcx, m2y = -2.0 * hcy, m2z = -2.0 * hcz;
     const double hh = fma(hcz, hcz, fma(hcy, hcy, hcx * hcx));
     double lo_c = -INFINITY, hi_c = -INFINITY;  // a lane outside the cluster: never inside, never too close to call
+    float m2xf = 0.0f, m2yf = 0.0f, m2zf = 0.0f, lo32 = -INFINITY, hi32 = -INFINITY;
     double gl = 0.0;  // the value c of a pair is within E of d2 - hh: c - G > gl = E - hh guarantees d2 > G (third class, below)
     if (DEP_H == 1) {
         const double Hm = sqrt(wave_max_d(inc[0] ? hh : 0.0)), Qm = sqrt(bex * bex + bey * bey + bez * bez) + R.rmax;
         const double E = 1e-13 * (Hm + Qm) * (Hm + Qm);
         if (inc[0]) { lo_c = (lim_lo[0] - hh) - E; hi_c = (lim_hi[0] - hh) + E; }
         gl = E - hh;
+        if (F32) {
+            // The same test in single precision (the "easy" rows, below).  With h', q' and |q'|^2 rounded to float and three
+            // float fused multiply-adds, the value differs from the exact |q'|^2 - 2 h'.q' by at most 2^-24 x (3 (Hm + Qm)^2
+            // for the three roundings of partial sums, each below (Hm + Qm)^2, + 4 Hm Qm for the rounded factors + Qm^2
+            // for the rounded square) <= 7 x 2^-24 (Hm + Qm)^2; the two bounds lose at most 2^-24 (Hm + Qm)^2 more when
+            // they are rounded to float.  E32 = 10 x 2^-24 (Hm + Qm)^2 on top of E; a pair closer than that is decided
+            // from the record itself in the reference's operation order (about one row in ten thousand).
+            const double E32 = DEP_E32_SCALE * 10.0 * 5.9604644775390625e-8 * (Hm + Qm) * (Hm + Qm) + 1e-30;
+            m2xf = -2.0f * (float)hcx; m2yf = -2.0f * (float)hcy; m2zf = -2.0f * (float)hcz;
+            if (inc[0]) { lo32 = (float)(lo_c - E32); hi32 = (float)(hi_c + E32); }
+        }
     }
     // Third class of staged records ("near"): the normal test passes for the whole cluster, but the record lies inside
     // the cluster's box or so close to it that the flatness test cannot be decided from the box alone.  For the whole
@@ -520,7 +540,20 @@ __global__ void __launch_bounds__(256) DEP_ATTR k_deposit_tiles(HpArrays hp, Rec
             if (in) {
                 double* row = s_row[wv][easy ? (int)mbcnt64(m_e) : (near ? __popcll(m_e) + (int)mbcnt64(m_n) : DEP_ROWS - 1 - (int)mbcnt64(m_f))];
                 const double f6 = p6, f7 = p7, f8 = p8;  // fixed point already (k_grid_scatter): integer-valued doubles
-                if (easy || near) {
+                if (F32 && easy) {
+                    // Two rows share 80 bytes: (x0 x1 y0 y1)(z0 z1 S0 S1) as floats -- q' and S = |q'|^2, laid out as the operand
+                    // pairs of packed single-precision multiply-adds -- then the flux of both rows as doubles; pairs are
+                    // packed from the start of the wavefront's staging area (pair k lies inside row k of the other
+                    // classes' layout, and those begin at row n_easy).  The record's place goes to s_idx.
+                    const double qx = p0 - bcx, qy = p1 - bcy, qz = p2 - bcz;
+                    const int slot = (int)mbcnt64(m_e);
+                    char* pb = (char*)&s_row[wv][0][0] + 80 * (slot >> 1) + 4 * (slot & 1);
+                    *(float*)pb = (float)qx; *(float*)(pb + 8) = (float)qy; *(float*)(pb + 16) = (float)qz;
+                    *(float*)(pb + 24) = (float)fma(qz, qz, fma(qy, qy, qx * qx));
+                    double* fb = (double*)((char*)&s_row[wv][0][0] + 80 * (slot >> 1) + 32 + 24 * (slot & 1));
+                    fb[0] = f6; fb[1] = f7; fb[2] = f8;
+                    s_idx[wv][slot] = p_r;
+                } else if (easy || near) {
                     const double qx = p0 - bcx, qy = p1 - bcy, qz = p2 - bcz;
                     row[0] = qx; row[1] = qy; row[2] = qz; row[3] = fma(qz, qz, fma(qy, qy, qx * qx));
                     row[4] = f6; row[5] = f7; row[6] = f8;
@@ -530,9 +563,13 @@ __global__ void __launch_bounds__(256) DEP_ATTR k_deposit_tiles(HpArrays hp, Rec
                     row[0] = p0; row[1] = p1; row[2] = p2; row[3] = p3; row[4] = p4; row[5] = p5;
                     row[6] = f6; row[7] = f7; row[8] = f8;
                 }
-                if (KEYS) row[ROW - 1] = __longlong_as_double((long long)p_key);
+                if (KEYS && !(F32 && easy)) row[ROW - 1] = __longlong_as_double((long long)p_key);
             }
             n_easy = __popcll(m_e); n_near = __popcll(m_n); n_full = __popcll(m_f);
+            if (F32 && (n_easy & 1) && lane == 0) {  // an odd row's partner: S = +inf is rejected by every lane and is never too close to call
+                char* pb = (char*)&s_row[wv][0][0] + 80 * (n_easy >> 1) + 4;
+                *(float*)pb = 0.0f; *(float*)(pb + 8) = 0.0f; *(float*)(pb + 16) = 0.0f; *(float*)(pb + 24) = INFINITY;
+            }
             sel_n = n_easy + n_near + n_full;
             if (STAMPS) { d_easy += (unsigned long long)n_easy; d_full += (unsigned long long)n_full; d_near += (unsigned long long)n_near; }
             const unsigned long long t1 = DSTAMP();
@@ -560,6 +597,51 @@ __global__ void __launch_bounds__(256) DEP_ATTR k_deposit_tiles(HpArrays hp, Rec
             }                                                                                                          \
         }
         unsigned long long und = 0ull;
+        if constexpr (F32) {
+            // Single precision, two rows per trip as ONE packed operation each (v_pk_fma_f32): the loop is bound by the vector
+            // instructions it issues (four cycles each per wavefront), 16 per trip in this form against 21 in double
+            // precision.  All of a trip's LDS reads are requested at its top (the empty asm uses the flux ahead of the
+            // tests: left to itself the compiler sinks those reads behind them, where each is waited for by itself).
+#define DEP_TAKE32(fx_, fy_, fz_, slot_)                                                                               \
+            {                                                                                                          \
+                ax[0] += (fx_); ay[0] += (fy_); az[0] += (fz_); am[0]++;                                               \
+                if (TAP) {                                                                                             \
+                    const unsigned long long ts = atomicAdd(tp.tap_n, 1ull);                                           \
+                    if ((int64_t)ts < tp.tap_cap) {                                                                    \
+                        tp.tap_key[ts] = (unsigned long long)__double_as_longlong(rec.f[(size_t)REC_ROW * s_idx[wv][slot_] + 9]); \
+                        tp.tap_pix[ts] = t.p[0];                                                                       \
+                    }                                                                                                  \
+                }                                                                                                      \
+            }
+            const char* eb = (const char*)&s_row[wv][0][0];
+            const v2f mx2 = {m2xf, m2xf}, my2 = {m2yf, m2yf}, mz2 = {m2zf, m2zf};
+            for (int ti = 0; ti < ne_u; ti += 2) {
+                const char* pb = eb + 40 * ti;
+                const v4f A = *(const v4f*)pb, B = *(const v4f*)(pb + 16);
+                v2d F0 = *(const v2d*)(pb + 32), F1 = *(const v2d*)(pb + 48), F2 = *(const v2d*)(pb + 64);
+                const v2f c = __builtin_elementwise_fma(mz2, B.xy, __builtin_elementwise_fma(my2, A.zw, __builtin_elementwise_fma(mx2, A.xy, B.zw)));
+                asm volatile("" : "+v"(F0), "+v"(F1), "+v"(F2));
+                const bool ok0 = c.x < lo32, ok1 = c.y < lo32;
+                und |= ~(ballot64(ok0) | ballot64(c.x > hi32)) | ~(ballot64(ok1) | ballot64(c.y > hi32));
+                if (ok0) DEP_TAKE32(F0.x, F0.y, F1.x, ti)
+                if (ok1) DEP_TAKE32(F1.y, F2.x, F2.y, ti + 1)
+            }
+            if ((und & ballot64(true)) != 0ull) {
+                // the pairs left out: decided from the record's position itself, in the reference's operation order
+                if (STAMPS) d_near_slow++;
+                for (int tj = 0; tj < ne_u; tj++) {
+                    const char* pb = eb + 80 * (tj >> 1) + 4 * (tj & 1);
+                    const float c0 = __builtin_fmaf(m2zf, *(const float*)(pb + 16), __builtin_fmaf(m2yf, *(const float*)(pb + 8), __builtin_fmaf(m2xf, *(const float*)pb, *(const float*)(pb + 24))));
+                    if (!(c0 < lo32) && !(c0 > hi32)) {
+                        const double* rp = rec.f + (size_t)REC_ROW * s_idx[wv][tj];
+                        const double e = len2(mk(t.x[0], t.y[0], t.z[0]) - mk(rp[0], rp[1], rp[2]));
+                        const double* fb = (const double*)(eb + 80 * (tj >> 1) + 32 + 24 * (tj & 1));
+                        if (inc[0] && (e < tp.gather_r2) && (e <= t.r2[0])) DEP_TAKE32(fb[0], fb[1], fb[2], tj)
+                    }
+                }
+            }
+#undef DEP_TAKE32
+        } else {
         int ti = 0;
         for (; ti + 1 < ne_u; ti += 2) {
             const double* r0 = s_row[wv][ti];
@@ -589,7 +671,11 @@ __global__ void __launch_bounds__(256) DEP_ATTR k_deposit_tiles(HpArrays hp, Rec
                 }
             }
         }
+        }
         // rows [n_easy, n_easy + n_near): the distance test and the pair's own flatness bound (see g_max above)
+#ifdef DEP_EXP_SKIP_NEAR
+        if (false)
+#endif
         if (nn_u > 0) {
             unsigned long long und2 = 0ull;
             for (int tn = ne_u; tn < ne_u + nn_u; tn++) {
@@ -626,6 +712,9 @@ __global__ void __launch_bounds__(256) DEP_ATTR k_deposit_tiles(HpArrays hp, Rec
         }
 #undef DEP_TAKE
         // rows [64 - n_full, 64): the full test
+#ifdef DEP_EXP_SKIP_FULL
+        if (false)
+#endif
         for (int ti = DEP_ROWS - nf_u; ti < DEP_ROWS; ti++) {
             const double* row = s_row[wv][ti];
             const d3 g0 = mk(row[3], row[4], row[5]);
