@@ -42,6 +42,8 @@ struct DepTile {
     int p[DEP_H]; bool live[DEP_H];
     double x[DEP_H], y[DEP_H], z[DEP_H], r2[DEP_H];
 };
+struct DepRegion;
+__device__ __forceinline__ double dep_box_dmin2(const DepRegion& R, double p0, double p1, double p2);
 __device__ __forceinline__ bool dep_load_tile(const HpArrays& hp, const TileParams& tp, int k, int lane, DepTile& t)
 {
     const int P = hp.P;
@@ -93,6 +95,11 @@ __device__ __forceinline__ bool dep_any(const unsigned long long (&m)[DEP_H])
 // region of a cluster: its bounding box and its largest radius (grown a little: the cell range must cover every
 // record a hitpoint of the cluster can accept)
 struct DepRegion { double bx0, bx1, by0, by1, bz0, bz1, rmax; int cx0, cx1, cy0, cy1, cz0, cz1; unsigned int n_inc; };
+__device__ __forceinline__ double dep_box_dmin2(const DepRegion& R, double p0, double p1, double p2)
+{
+    const double nx = fmax(fmax(R.bx0 - p0, p0 - R.bx1), 0.0), ny = fmax(fmax(R.by0 - p1, p1 - R.by1), 0.0), nz = fmax(fmax(R.bz0 - p2, p2 - R.bz1), 0.0);
+    return nx * nx + ny * ny + nz * nz;
+}
 __device__ __forceinline__ DepRegion dep_region(const DepTile& t, const bool (&inc)[DEP_H], const TileParams& tp)
 {
     const double BIG = 1e300;
@@ -291,12 +298,16 @@ __global__ void __launch_bounds__(256) DEP_ATTR k_deposit_tiles(HpArrays hp, Rec
     // a staged record of the full test: position, geometric normal, fixed-point flux (integer-valued doubles); of the distance-only
     // test: position about the cluster's centre, its square, flux, position; [ROW - 1: key bits]
     __shared__ __align__(16) double s_row[4][DEP_ROWS][ROW];
+    __shared__ __align__(16) float s_fp[4][DEP_ROWS / 2][12];  // (single-precision full test: two rows share (x0 x1 y0 y1)(z0 z1 gx0 gx1)(gy0 gy1 gz0 gz1))
     __shared__ uint32_t s_idx[4][DEP_ROWS];  // (single-precision rows: the record's place, for the pairs decided from the record itself)
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int P = hp.P;
     const double thr = tp.gather_r2 * 0.01;
     const double band_rel = 1e-9 + 8e-15 / thr;
     const double thr2_lo = thr * thr * (1.0 - band_rel), thr2_hi = thr * thr * (1.0 + band_rel);
+    // (the two constants of the classification, with their margins folded in; pinned: uniform values computed by vector
+    // instructions otherwise sit in vector registers, and these two were spilled and re-read from scratch memory per group)
+    const double c_rej = pin_scalar_d(thr2_hi * (1.0 + 1e-9) * (1.0 + 1e-12)), c_easy = pin_scalar_d(thr2_lo * (1.0 - 1e-9));
     const double inv_thr2_up = (1.0 / thr2_lo) * (1.0 + 4e-9);  // x this >= x / (thr2_lo (1 - 1e-9)), with room for the roundings
     const unsigned int n_items = q[0];
     const unsigned int n_waves = gridDim.x * 4u;
@@ -421,6 +432,7 @@ __global__ void __launch_bounds__(256) DEP_ATTR k_deposit_tiles(HpArrays hp, Rec
     const double hh = fma(hcz, hcz, fma(hcy, hcy, hcx * hcx));
     double lo_c = -INFINITY, hi_c = -INFINITY;  // a lane outside the cluster: never inside, never too close to call
     float m2xf = 0.0f, m2yf = 0.0f, m2zf = 0.0f, lo32 = -INFINITY, hi32 = -INFINITY;
+    float hnxf = 0.0f, hnyf = 0.0f, hnzf = 0.0f, dlo32 = -1.0f, dhi32 = -1.0f, ef32 = 0.0f, tlo2f = 0.0f, thi2f = 0.0f;  // (-1: never inside, never too close to call)
     double gl = 0.0;  // the value c of a pair is within E of d2 - hh: c - G > gl = E - hh guarantees d2 > G (third class, below)
     if (DEP_H == 1) {
         const double Hm = sqrt(wave_max_d(inc[0] ? hh : 0.0)), Qm = sqrt(bex * bex + bey * bey + bez * bez) + R.rmax;
@@ -437,6 +449,25 @@ __global__ void __launch_bounds__(256) DEP_ATTR k_deposit_tiles(HpArrays hp, Rec
             const double E32 = DEP_E32_SCALE * 10.0 * 5.9604644775390625e-8 * (Hm + Qm) * (Hm + Qm) + 1e-30;
             m2xf = -2.0f * (float)hcx; m2yf = -2.0f * (float)hcy; m2zf = -2.0f * (float)hcz;
             if (inc[0]) { lo32 = (float)(lo_c - E32); hi32 = (float)(hi_c + E32); }
+            // The full test in single precision (below), about the same centre.  With u = 2^-24, D = Hm + Qm and e = q' - h':
+            // the computed e is within 3.5 u D of its value (as a vector), so |e|^2 within 7 u D |e| + 3 u |e|^2 and g.e
+            // (|g| = 1) within 4 u |e| + 3.5 u D; then F = thr^2 |e|^2 - (g.e)^2 is within
+            //   u [(7 + 7 thr^2) D |e| + (10 + 5 thr^2) |e|^2] + O(u^2 D^2),   and with D |e| <= (D^2 / 32 + 32 |e|^2) / 2:
+            //   A D^2 + B |e|^2,   A = u (7 + 7 thr^2) / 64,   B = u (122 + 117 thr^2)
+            // (a band proportional to D^2 alone would send every pair much closer than the cluster's size to the fallback).
+            // Both are taken half as wide again, B also covers the rounding of thr^2 -+ B to float and the relative 1e-9
+            // band of the double-precision form.  flat for sure: (thr^2 - B) |e|^2 - (g.e)^2 > A D^2; not flat for sure:
+            // (thr^2 + B) |e|^2 - (g.e)^2 < -A D^2.  The distance: within 1.5 (7 u D sqrt(lim) + 3 u lim) of a lane's bound
+            // `lim` (plus E for the centring); n.g of unit vectors: within 3e-7, band 4e-6.  A pair inside a band sends
+            // its row to the reference's operation order in double precision, as before.
+            const double u_ = 5.9604644775390625e-8 * DEP_E32_SCALE, D2 = (Hm + Qm) * (Hm + Qm), t2_ = thr * thr;
+            const double Bf = 1.5 * u_ * (122.0 + 117.0 * t2_) + 2.0 * u_ * t2_ + 2.0 * band_rel * t2_;
+            ef32 = (float)((1.5 * u_ * (7.0 + 7.0 * t2_) / 64.0 + 1e-12) * D2 + 1e-30);
+            tlo2f = (float)(t2_ - Bf); thi2f = (float)(t2_ + Bf);
+            hnxf = (float)hn[0].x; hnyf = (float)hn[0].y; hnzf = (float)hn[0].z;
+            const double lim_ = fmin(t.r2[0], tp.gather_r2);
+            const double Ed = 1.5 * u_ * (7.0 * (Hm + Qm) * sqrt(lim_) + 3.0 * lim_) + E + 1e-30;
+            if (inc[0]) { dlo32 = (float)(lim_lo[0] - Ed); dhi32 = (float)(lim_hi[0] + Ed); }
         }
     }
     // Third class of staged records ("near"): the normal test passes for the whole cluster, but the record lies inside
@@ -518,21 +549,24 @@ __global__ void __launch_bounds__(256) DEP_ATTR k_deposit_tiles(HpArrays hp, Rec
             bool in = false, easy = false, near = false;
             double G = 0.0;
             if (p_has) {
-                const double nx = fmax(fmax(R.bx0 - p0, p0 - R.bx1), 0.0), ny = fmax(fmax(R.by0 - p1, p1 - R.by1), 0.0), nz = fmax(fmax(R.bz0 - p2, p2 - R.bz1), 0.0);
-                const double dmin2 = nx * nx + ny * ny + nz * nz;
+                // distance to the cluster's box from its centre and half extents (the half extents carry a margin upwards, so the
+                // nearest point comes out no farther and the farthest no nearer than they are: every use below is on the safe side)
+                const double ux = p0 - bcx, uy = p1 - bcy, uz = p2 - bcz;
+                const double nx = fmax(fabs(ux) - bex, 0.0), ny = fmax(fabs(uy) - bey, 0.0), nz = fmax(fabs(uz) - bez, 0.0);
+                const double dmin2 = DEP_H == 1 ? nx * nx + ny * ny + nz * nz : dep_box_dmin2(R, p0, p1, p2);  // (two hitpoints per lane: no centre is made)
                 in = dmin2 <= rmax2;
                 if (DEP_H == 1 && in) {
-                    const double fx_ = fmax(p0 - R.bx0, R.bx1 - p0), fy_ = fmax(p1 - R.by0, R.by1 - p1), fz_ = fmax(p2 - R.bz0, R.bz1 - p2);
-                    const double dmax2 = (fx_ * fx_ + fy_ * fy_ + fz_ * fz_) * (1.0 + 1e-12);
+                    const double fx_ = fabs(ux) + bex, fy_ = fabs(uy) + bey, fz_ = fabs(uz) + bez;
+                    const double dmax2 = fx_ * fx_ + fy_ * fy_ + fz_ * fz_;  // (its margin upwards is in c_rej)
                     const double nd = nbar.x * p3 + nbar.y * p4 + nbar.z * p5;                    // a hitpoint's n.g lies within ndev of it
-                    const double sc = fabs(p3 * (bcx - p0) + p4 * (bcy - p1) + p5 * (bcz - p2));  // |g.(h - q)| lies within `spread` of it
+                    const double sc = fabs(p3 * ux + p4 * uy + p5 * uz);                          // |g.(h - q)| lies within `spread` of it
                     const double spread = fabs(p3) * bex + fabs(p4) * bey + fabs(p5) * bez;
                     const double f_hi = (sc + spread) * (1.0 + 1e-9), f_lo = fmax(sc - spread, 0.0) * (1.0 - 1e-9);
-                    const bool rej = nd + ndev < 1e-3 - 1e-9 || f_lo * f_lo > thr2_hi * dmax2 * (1.0 + 1e-9);
+                    const bool rej = nd + ndev < 1e-3 - 1e-9 || f_lo * f_lo > c_rej * dmax2;
                     const bool n_all = nd - ndev > 1e-3 + 1e-9;
-                    easy = !rej && n_all && dmin2 > 0.0 && f_hi * f_hi < thr2_lo * dmin2 * (1.0 - 1e-9);
+                    easy = !rej && n_all && dmin2 > 0.0 && f_hi * f_hi < c_easy * dmin2;
                     G = (f_hi * f_hi) * inv_thr2_up;
-                    near = !rej && !easy && n_all && G < g_max;
+                    near = !F32 && !rej && !easy && n_all && G < g_max;  // (single precision: those records take the full test, which costs little there)
                     in = !rej;
                 }
             }
@@ -562,10 +596,20 @@ __global__ void __launch_bounds__(256) DEP_ATTR k_deposit_tiles(HpArrays hp, Rec
                 } else {
                     row[0] = p0; row[1] = p1; row[2] = p2; row[3] = p3; row[4] = p4; row[5] = p5;
                     row[6] = f6; row[7] = f7; row[8] = f8;
+                    if (F32) {
+                        const int j = (int)mbcnt64(m_f);
+                        float* pp = &s_fp[wv][j >> 1][j & 1];
+                        pp[0] = (float)(p0 - bcx); pp[2] = (float)(p1 - bcy); pp[4] = (float)(p2 - bcz);
+                        pp[6] = (float)p3; pp[8] = (float)p4; pp[10] = (float)p5;
+                    }
                 }
                 if (KEYS && !(F32 && easy)) row[ROW - 1] = __longlong_as_double((long long)p_key);
             }
             n_easy = __popcll(m_e); n_near = __popcll(m_n); n_full = __popcll(m_f);
+            if (F32 && (n_full & 1) && lane == 0) {  // an odd full-test row's partner: at infinity (outside every radius), normal zero
+                float* pp = &s_fp[wv][n_full >> 1][1];
+                pp[0] = INFINITY; pp[2] = 0.0f; pp[4] = 0.0f; pp[6] = 0.0f; pp[8] = 0.0f; pp[10] = 0.0f;
+            }
             if (F32 && (n_easy & 1) && lane == 0) {  // an odd row's partner: S = +inf is rejected by every lane and is never too close to call
                 char* pb = (char*)&s_row[wv][0][0] + 80 * (n_easy >> 1) + 4;
                 *(float*)pb = 0.0f; *(float*)(pb + 8) = 0.0f; *(float*)(pb + 16) = 0.0f; *(float*)(pb + 24) = INFINITY;
@@ -634,9 +678,11 @@ __global__ void __launch_bounds__(256) DEP_ATTR k_deposit_tiles(HpArrays hp, Rec
                     const float c0 = __builtin_fmaf(m2zf, *(const float*)(pb + 16), __builtin_fmaf(m2yf, *(const float*)(pb + 8), __builtin_fmaf(m2xf, *(const float*)pb, *(const float*)(pb + 24))));
                     if (!(c0 < lo32) && !(c0 > hi32)) {
                         const double* rp = rec.f + (size_t)REC_ROW * s_idx[wv][tj];
-                        const double e = len2(mk(t.x[0], t.y[0], t.z[0]) - mk(rp[0], rp[1], rp[2]));
+                        int pr_ = t.p[0];  // (the hitpoint is read again: its double-precision state is not kept in registers through the loops)
+                        asm volatile("" : "+v"(pr_));
+                        const double e = len2(mk(hp.pos[pr_], hp.pos[P + pr_], hp.pos[2 * P + pr_]) - mk(rp[0], rp[1], rp[2]));
                         const double* fb = (const double*)(eb + 80 * (tj >> 1) + 32 + 24 * (tj & 1));
-                        if (inc[0] && (e < tp.gather_r2) && (e <= t.r2[0])) DEP_TAKE32(fb[0], fb[1], fb[2], tj)
+                        if (inc[0] && (e < tp.gather_r2) && (e <= hp.r2[pr_])) DEP_TAKE32(fb[0], fb[1], fb[2], tj)
                     }
                 }
             }
@@ -676,7 +722,7 @@ __global__ void __launch_bounds__(256) DEP_ATTR k_deposit_tiles(HpArrays hp, Rec
 #ifdef DEP_EXP_SKIP_NEAR
         if (false)
 #endif
-        if (nn_u > 0) {
+        if (!F32 && nn_u > 0) {
             unsigned long long und2 = 0ull;
             for (int tn = ne_u; tn < ne_u + nn_u; tn++) {
                 const double* r0 = s_row[wv][tn];
@@ -715,6 +761,71 @@ __global__ void __launch_bounds__(256) DEP_ATTR k_deposit_tiles(HpArrays hp, Rec
 #ifdef DEP_EXP_SKIP_FULL
         if (false)
 #endif
+        if constexpr (F32) {
+            // Single precision first, two rows per packed instruction (the loop is bound by the vector instructions issued:
+            // ~19 per row in this form against ~45); a row with a pair inside one of the bands is evaluated again in the
+            // reference's operation order from its double-precision row.
+            const v2f mx2 = {m2xf, m2xf}, my2 = {m2yf, m2yf}, mz2 = {m2zf, m2zf}, half2 = {0.5f, 0.5f};
+            const v2f nx2 = {hnxf, hnxf}, ny2 = {hnyf, hnyf}, nz2 = {hnzf, hnzf}, tl2 = {tlo2f, tlo2f}, th2 = {thi2f, thi2f};
+            for (int tj = 0; tj < nf_u; tj += 2) {
+                const bool two = tj + 1 < nf_u;
+                const double* rowA = s_row[wv][DEP_ROWS - 1 - tj];
+                const double* rowB = s_row[wv][two ? DEP_ROWS - 2 - tj : DEP_ROWS - 1 - tj];
+                const float* pp = &s_fp[wv][tj >> 1][0];
+                const v4f PA = *(const v4f*)pp, PB = *(const v4f*)(pp + 4), PC = *(const v4f*)(pp + 8);
+                double fAx = rowA[6], fAy = rowA[7], fAz = rowA[8], fBx = rowB[6], fBy = rowB[7], fBz = rowB[8];
+                const v2f ex = __builtin_elementwise_fma(mx2, half2, PA.xy), ey = __builtin_elementwise_fma(my2, half2, PA.zw), ez = __builtin_elementwise_fma(mz2, half2, PB.xy);  // q' - h'
+                const v2f gx = PB.zw, gy = PC.xy, gz = PC.zw;
+                const v2f d2 = __builtin_elementwise_fma(ez, ez, __builtin_elementwise_fma(ey, ey, ex * ex));
+                const v2f s1 = __builtin_elementwise_fma(gz, ez, __builtin_elementwise_fma(gy, ey, gx * ex));
+                const v2f nd = __builtin_elementwise_fma(nz2, gz, __builtin_elementwise_fma(ny2, gy, nx2 * gx));
+                const v2f l2 = s1 * s1;
+                const v2f sp = __builtin_elementwise_fma(tl2, d2, -l2), sn = __builtin_elementwise_fma(th2, d2, -l2);  // (thr^2 -+ B) d2 - (g.e)^2
+                asm volatile("" : "+v"(fAx), "+v"(fAy), "+v"(fAz), "+v"(fBx), "+v"(fBy), "+v"(fBz));
+                bool okA = d2.x < dlo32 && nd.x > 1e-3f + 4e-6f && sp.x > ef32;
+                bool okB = d2.y < dlo32 && nd.y > 1e-3f + 4e-6f && sp.y > ef32;
+                const bool unA = inc[0] && !okA && !(d2.x > dhi32 || nd.x < 1e-3f - 4e-6f || sn.x < -ef32);
+                const bool unB = inc[0] && !okB && !(d2.y > dhi32 || nd.y < 1e-3f - 4e-6f || sn.y < -ef32);
+#define DEP_EXACT(rowp, okv)                                                                                           \
+                {                                                                                                      \
+                    /* (the hitpoint is read again: its double-precision state is not kept in registers through the loops) */ \
+                    int pr_ = t.p[0];                                                                                  \
+                    asm volatile("" : "+v"(pr_));                                                                      \
+                    const d3 hp_ = mk(hp.pos[pr_], hp.pos[P + pr_], hp.pos[2 * P + pr_]), hn_ = mk(hp.nrm[pr_], hp.nrm[P + pr_], hp.nrm[2 * P + pr_]); \
+                    const double hr2_ = hp.r2[pr_];  /* (all seven loads at once, not one behind each test) */         \
+                    const d3 g0 = mk((rowp)[3], (rowp)[4], (rowp)[5]);                                                 \
+                    const d3 dir = hp_ - mk((rowp)[0], (rowp)[1], (rowp)[2]);                                          \
+                    const double d2e = len2(dir);                                                                      \
+                    const bool o = inc[0] & (d2e < tp.gather_r2) & (d2e <= hr2_) & (dot(hn_, g0) > 1e-3);              \
+                    const double s1e = dot(g0, dir);                                                                   \
+                    const double l2 = s1e * s1e, rhs = thr * thr * d2e;                                                \
+                    const double band = rhs * band_rel;                                                                \
+                    bool flat = l2 < rhs - band;                                                                       \
+                    if (o && !flat && !(l2 > rhs + band)) {                                                            \
+                        const double dt = dot(g0, dir / sqrt(d2e)); /* NaN at d2 == 0: rejected as in the reference */ \
+                        flat = fabs(dt) <= thr;                                                                        \
+                    }                                                                                                  \
+                    okv = o && flat;                                                                                   \
+                }
+                if (ballot64(unA) != 0ull) { if (STAMPS) d_near_slow++; DEP_EXACT(rowA, okA) }
+                if (two && ballot64(unB) != 0ull) { if (STAMPS) d_near_slow++; DEP_EXACT(rowB, okB) }
+#undef DEP_EXACT
+                if (okA) {
+                    ax[0] += fAx; ay[0] += fAy; az[0] += fAz; am[0]++;
+                    if (TAP) {
+                        const unsigned long long ts = atomicAdd(tp.tap_n, 1ull);
+                        if ((int64_t)ts < tp.tap_cap) { tp.tap_key[ts] = (unsigned long long)__double_as_longlong(rowA[ROW - 1]); tp.tap_pix[ts] = t.p[0]; }
+                    }
+                }
+                if (two && okB) {
+                    ax[0] += fBx; ay[0] += fBy; az[0] += fBz; am[0]++;
+                    if (TAP) {
+                        const unsigned long long ts = atomicAdd(tp.tap_n, 1ull);
+                        if ((int64_t)ts < tp.tap_cap) { tp.tap_key[ts] = (unsigned long long)__double_as_longlong(rowB[ROW - 1]); tp.tap_pix[ts] = t.p[0]; }
+                    }
+                }
+            }
+        } else
         for (int ti = DEP_ROWS - nf_u; ti < DEP_ROWS; ti++) {
             const double* row = s_row[wv][ti];
             const d3 g0 = mk(row[3], row[4], row[5]);

@@ -370,7 +370,8 @@ static int deposit_tiles(sppm_ctx* c)
     // sort, the tracer, the binning -- gets the other slots, and late in a render the next deposit waits for that eye
     // pass, not for this kernel.  Measured with fixed counts (photons/s at 20 / 256 passes, before the walk by rows of
     // cells): 768 workgroups 267M / 305M, 704 266M / 310M, 640 260M / 313M, 576 249M / 317M, 512 237M / 313M; with the
-    // walk by rows the kernel is shorter and the late optimum moved from 576 to 512.
+    // walk by rows and the single-precision tests the kernel is shorter and the late optimum moved from 576 to 448
+    // (DESIGN.md section 3c).
     int dep_blocks = 256 * 3;
     if (c->pairs_per_photon > 0.0) {
         const double t = std::min(1.0, std::max(0.0, (c->pairs_per_photon - c->dep_light) / (c->dep_heavy - c->dep_light)));
