@@ -276,9 +276,6 @@ __global__ void __launch_bounds__(256) k_items_place(const unsigned long long* _
 #define DEP_ATTR __attribute__((amdgpu_waves_per_eu(DEP_WAVES, DEP_WAVES)))
 #define DEP_FLUSH_ROWS 2048  // staged rows after which the double sums move to the 64-bit integers (2048 x 2^41 = 2^52)
 #ifndef DEP_NEAR_MAX
-typedef double v2d __attribute__((ext_vector_type(2)));
-typedef float v2f __attribute__((ext_vector_type(2)));
-typedef float v4f __attribute__((ext_vector_type(4)));
 #define DEP_NEAR_MAX 1e-4
 #ifndef DEP_E32_SCALE
 #define DEP_E32_SCALE 1.0  // (a build with 1e4 here sends every hundredth pair through the exact fallback: how that path was validated)

@@ -156,6 +156,10 @@ __device__ __forceinline__ double wave_min_d(double v)
     return rl_d(v, 63);
 }
 
+// native vectors: two floats are one operand of the packed single-precision instructions (v_pk_fma_f32 ...)
+typedef double v2d __attribute__((ext_vector_type(2)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
 // inclusive prefix sum over the wavefront, the same way: Hillis-Steele inside each row of 16 lanes (a lane whose source
 // lies outside its row adds 0), then lane 15 of rows 0 and 2 into rows 1 and 3, then lane 31 into rows 2 and 3.
 // Every lane must be active.

@@ -357,6 +357,9 @@ __global__ void __launch_bounds__(256) k_items_scatter(const unsigned long long*
 #endif
 // UNIT: classic PPM -- the record's flux is applied as it is (no hitpoint weight or colour),
 // src/progressive_photonmapping.h:385-387
+#ifndef GT_E32_SCALE
+#define GT_E32_SCALE 1.0  // (a build with 3e3 here sends a large share of the candidates through the exact fallback: how that path was validated)
+#endif
 template <bool STAMPS, bool UNIT>
 __global__ void __launch_bounds__(256) GATHER_WAVES_ATTR k_gather_tiles(HpArrays hp, DevScene sc, RecArrays rec, const uint32_t* __restrict__ cell_start,
                                                       TileParams tp, const uint32_t* __restrict__ items, unsigned int* __restrict__ q,
@@ -365,6 +368,7 @@ __global__ void __launch_bounds__(256) GATHER_WAVES_ATTR k_gather_tiles(HpArrays
     __shared__ unsigned long long s_key[4][64];
     __shared__ uint32_t s_rec[4][64];
     __shared__ double s_row[4][64][10];  // the round's candidates in key order: position, geometric normal, key, flux
+    __shared__ __align__(16) float s_fp[4][32][12];  // the same in single precision about the cluster's centre, two candidates per entry: (x0 x1 y0 y1)(z0 z1 gx0 gx1)(gy0 gy1 gz0 gz1)
     const unsigned long long t_entry = STAMPS ? wall_clock64() : 0ull;  // 100 MHz, one clock for the whole device
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int P = hp.P;
@@ -437,6 +441,26 @@ __global__ void __launch_bounds__(256) GATHER_WAVES_ATTR k_gather_tiles(HpArrays
     const double bx0 = wave_min_perm_d(inc ? hpos.x : BIG), bx1 = wave_max_perm_d(inc ? hpos.x : -BIG);
     const double by0 = wave_min_perm_d(inc ? hpos.y : BIG), by1 = wave_max_perm_d(inc ? hpos.y : -BIG);
     const double bz0 = wave_min_perm_d(inc ? hpos.z : BIG), bz1 = wave_max_perm_d(inc ? hpos.z : -BIG);
+    // Phase 1 in single precision (below): everything about the box's centre.  D bounds |h'| + |q'| for every hitpoint of the
+    // cluster and every candidate its region can hold (the region is the box grown by the largest radius, which only shrinks).
+    const double cbx = 0.5 * (bx0 + bx1), cby = 0.5 * (by0 + by1), cbz = 0.5 * (bz0 + bz1);
+    const v2f nhx = {(float)(cbx - hpos.x), (float)(cbx - hpos.x)}, nhy = {(float)(cby - hpos.y), (float)(cby - hpos.y)}, nhz = {(float)(cbz - hpos.z), (float)(cbz - hpos.z)};  // -h'
+    const v2f fnx = {(float)hn.x, (float)hn.x}, fny = {(float)hn.y, (float)hn.y}, fnz = {(float)hn.z, (float)hn.z};
+    float g_lo = 0.0f, g_hi = 0.0f, e_d = 0.0f, e_a = 0.0f, t_lo = 0.0f, t_hi = 0.0f;
+    {
+        const double r0 = wave_max_perm_d(inc ? sqrt(fmin(r2, tp.gather_r2)) * (1.0 + 1e-9) + 1e-9 : 0.0);
+        const double hx_ = 0.5 * (bx1 - bx0), hy_ = 0.5 * (by1 - by0), hz_ = 0.5 * (bz1 - bz0);
+        const double Hm = sqrt(hx_ * hx_ + hy_ * hy_ + hz_ * hz_) * (1.0 + 1e-9) + 1e-9;
+        const double Qm = sqrt((hx_ + r0) * (hx_ + r0) + (hy_ + r0) * (hy_ + r0) + (hz_ + r0) * (hz_ + r0)) * (1.0 + 1e-9) + 1e-9;
+        const double D = Hm + Qm, u_ = 5.9604644775390625e-8 * GT_E32_SCALE, t2_ = thr * thr;
+        // error bands: sppm_deposit.hpp (the full test in single precision) derives them; the distance test against the
+        // search radius is within 1.5 (7 u D sqrt(R^2) + 3 u R^2) + the centring's roundings
+        const double Ed = 1.5 * u_ * (7.0 * D * sqrt(tp.gather_r2) + 3.0 * tp.gather_r2) + 1e-13 * D * D + 1e-30;
+        const double Bf = 1.5 * u_ * (122.0 + 117.0 * t2_) + 2.0 * u_ * t2_ + 2.0 * band_rel * t2_;
+        g_lo = (float)(tp.gather_r2 - Ed); g_hi = (float)(tp.gather_r2 + Ed); e_d = (float)(Ed * (1.0 + 1e-6));
+        e_a = (float)((1.5 * u_ * (7.0 + 7.0 * t2_) / 64.0 + 1e-12) * D * D + 1e-30);
+        t_lo = (float)(t2_ - Bf); t_hi = (float)(t2_ + Bf);
+    }
     for (int s = 0; s < tp.g.S; s++) {
         // region of this slab: bounding box grown by the largest radius any lane can still accept at
         const double rr = inc ? sqrt(fmin(r2, tp.gather_r2)) * (1.0 + 1e-9) + 1e-9 : 0.0;
@@ -530,6 +554,13 @@ __global__ void __launch_bounds__(256) GATHER_WAVES_ATTR k_gather_tiles(HpArrays
                     double* row = s_row[wv][rank];  // q, g0, key, flux
                     row[0] = q.x; row[1] = q.y; row[2] = q.z; row[3] = gn.x; row[4] = gn.y; row[5] = gn.z;
                     row[6] = __longlong_as_double((long long)mykey); row[7] = pf.x; row[8] = pf.y; row[9] = pf.z;
+                    float* pp = &s_fp[wv][rank >> 1][rank & 1];
+                    pp[0] = (float)(q.x - cbx); pp[2] = (float)(q.y - cby); pp[4] = (float)(q.z - cbz);
+                    pp[6] = (float)gn.x; pp[8] = (float)gn.y; pp[10] = (float)gn.z;
+                }
+                if ((sel_n & 1) && lane == 63) {  // an odd candidate's partner: at infinity (outside every radius), normal zero
+                    float* pp = &s_fp[wv][sel_n >> 1][1];
+                    pp[0] = INFINITY; pp[2] = 0.0f; pp[4] = 0.0f; pp[6] = 0.0f; pp[8] = 0.0f; pp[10] = 0.0f;
                 }
                 __builtin_amdgcn_wave_barrier();
                 const unsigned long long ts2 = TSTAMP();
@@ -539,42 +570,51 @@ __global__ void __launch_bounds__(256) GATHER_WAVES_ATTR k_gather_tiles(HpArrays
                 // The row of candidate t+1 is read while candidate t is tested.
                 unsigned long long todo = 0;
                 const int sel_u = __builtin_amdgcn_readfirstlane(sel_n);
-                double n0, n1, n2, n3, n4, n5, n6;
-                {
-                    const double* row = s_row[wv][0];
-                    n0 = row[0]; n1 = row[1]; n2 = row[2]; n3 = row[3]; n4 = row[4]; n5 = row[5]; n6 = row[6];
+                // In single precision first, two candidates per packed instruction (the loop is bound by the vector
+                // instructions it issues); a candidate with a lane inside one of the error bands is tested again in the
+                // reference's operation order from its double-precision row, for every lane.
+                const float r2_hi = (float)(r2 * (1.0 + 1e-6)) + e_d;  // (r2 only shrinks: a superset here, the walk tests d2 <= r2 exactly)
+                const v2f tl2 = {t_lo, t_lo}, th2 = {t_hi, t_hi};
+#define GT_EXACT(tt, okv)                                                                                              \
+                {                                                                                                      \
+                    const double* row = s_row[wv][tt];                                                                 \
+                    const d3 qq = mk(row[0], row[1], row[2]), g0 = mk(row[3], row[4], row[5]);                         \
+                    const d3 dir = hpos - qq;                                                                          \
+                    const double d2 = len2(dir);                                                                       \
+                    bool o_ = inc && (d2 < tp.gather_r2) && (d2 <= r2) && (dot(hn, g0) > 1e-3);                        \
+                    const double s1 = dot(g0, dir);  /* (its square: the orientation of the normal does not matter) */ \
+                    const double lhs = s1 * s1, rhs = thr * thr * d2;                                                  \
+                    const double band = rhs * band_rel;                                                                \
+                    bool flat = lhs < rhs - band;                                                                      \
+                    if (o_ && !flat && !(lhs > rhs + band)) {                                                          \
+                        const unsigned int klow = (unsigned int)__double_as_longlong(row[6]);                          \
+                        const d3 on = (klow & 1u) ? g0 * -1.0 : g0;                                                    \
+                        const double dt = dot(on, dir / sqrt(d2));  /* NaN at d2 == 0: rejected as in the reference */ \
+                        flat = fabs(dt) <= thr;                                                                        \
+                    }                                                                                                  \
+                    okv = o_ && flat;                                                                                  \
                 }
-                for (int t = 0; t < sel_u; t++) {
-                    const d3 qq = mk(n0, n1, n2), g0 = mk(n3, n4, n5);
-                    const unsigned int klow = (unsigned int)__double_as_longlong(n6);
-                    {
-                        const double* row = s_row[wv][t + 1 < sel_u ? t + 1 : t];
-                        n0 = row[0]; n1 = row[1]; n2 = row[2]; n3 = row[3]; n4 = row[4]; n5 = row[5]; n6 = row[6];
-                    }
-                    const d3 dir = hpos - qq;
-                    const double d2 = len2(dir);
-                    // r2 only shrinks: d2 <= r2 here accepts a superset of what phase 2 accepts
-                    bool ok = inc && (d2 < tp.gather_r2) && (d2 <= r2) && (dot(hn, g0) > 1e-3);
-                    if (__ballot(ok) == 0) continue;
-                    const d3 on = (klow & 1u) ? g0 * -1.0 : g0;
-                    {   // flatness filter |dot(on, dir/sqrt(d2))| <= thr, decided without the square root
-                        // and the three divisions unless the squared form is within rounding of the bound
-                        const double s1 = dot(on, dir);
-                        const double lhs = s1 * s1, rhs = thr * thr * d2;
-                        const double band = rhs * band_rel;
-                        const bool sure_pass = lhs < rhs - band, sure_fail = lhs > rhs + band;
-                        bool flat = sure_pass;
-                        const bool unsure = ok && !sure_pass && !sure_fail;
-                        if (__ballot(unsure) != 0) {
-                            if (unsure) {
-                                const double dt = dot(on, dir / sqrt(d2));  // NaN at d2 == 0: rejected as in the reference
-                                flat = fabs(dt) <= thr;
-                            }
-                        }
-                        ok = ok && flat;
-                    }
-                    if (ok) todo |= 1ull << t;
+                for (int t = 0; t < sel_u; t += 2) {
+                    const float* pp = &s_fp[wv][t >> 1][0];
+                    const v4f PA = *(const v4f*)pp, PB = *(const v4f*)(pp + 4), PC = *(const v4f*)(pp + 8);
+                    const v2f ex = PA.xy + nhx, ey = PA.zw + nhy, ez = PB.xy + nhz;  // q' - h'
+                    const v2f gx = PB.zw, gy = PC.xy, gz = PC.zw;
+                    const v2f d2 = __builtin_elementwise_fma(ez, ez, __builtin_elementwise_fma(ey, ey, ex * ex));
+                    const v2f s1 = __builtin_elementwise_fma(gz, ez, __builtin_elementwise_fma(gy, ey, gx * ex));
+                    const v2f nd = __builtin_elementwise_fma(fnz, gz, __builtin_elementwise_fma(fny, gy, fnx * gx));
+                    const v2f l2 = s1 * s1;
+                    const v2f sp = __builtin_elementwise_fma(tl2, d2, -l2), sn = __builtin_elementwise_fma(th2, d2, -l2);
+                    bool ok0 = d2.x <= r2_hi && d2.x < g_lo && nd.x > 1e-3f + 4e-6f && sp.x > e_a;
+                    bool ok1 = d2.y <= r2_hi && d2.y < g_lo && nd.y > 1e-3f + 4e-6f && sp.y > e_a;
+                    const bool un0 = inc && !ok0 && !(d2.x > r2_hi || d2.x > g_hi || nd.x < 1e-3f - 4e-6f || sn.x < -e_a);
+                    const bool un1 = inc && !ok1 && !(d2.y > r2_hi || d2.y > g_hi || nd.y < 1e-3f - 4e-6f || sn.y < -e_a);
+                    ok0 = ok0 && inc; ok1 = ok1 && inc;
+                    if (__ballot(un0) != 0) GT_EXACT(t, ok0)
+                    if (t + 1 < sel_u && __ballot(un1) != 0) GT_EXACT(t + 1, ok1)
+                    if (ok0) todo |= 1ull << t;
+                    if (ok1 && t + 1 < sel_u) todo |= 2ull << t;
                 }
+#undef GT_EXACT
                 // ---- phase 2, every lane walks ITS OWN candidates in key order: only accepted pairs cost
                 // an update, and the trip count is the longest list of the wave, not the candidate count.
                 // A lane with nothing to do adds zero flux and scales by one, which changes nothing.
