@@ -379,8 +379,8 @@ def report(args, world, rule, r, table_name):
             "alg_bytes_per_launch": alg_bytes / g_launch, "alg_GBps": alg_bytes / max(g_ns, 1),
             "update_bytes_GBps_at_60B": 60.0 * upd0 / max(g_ns, 1), "update_bytes_frac_of_hbm_peak": 60.0 * upd0 / max(g_ns, 1) / 8000.0,
             "note": "rank 0; bound = the vector ALU: the committed SQ counters (profiles/r03_pmc_rule%d.json) show it as the busiest unit of the kernel (VALU busy %s "
-                    "of the time every SIMD is occupied, LDS %s, HBM a few percent of 8 TB/s), so the roofline is the FP64 vector peak; the kernel does not "
-                    "saturate the pipe -- three to four wavefronts of 128 registers per SIMD leave dependent instructions and LDS round trips exposed, and every second instruction issued is scalar or LDS work around the arithmetic.  achieved = 23 flop x "
+                    "of the time every SIMD is occupied, LDS %s, HBM a few percent of 8 TB/s) and the pair loops are bound by the vector instructions they issue (ablation, DESIGN.md 3c), so the roofline is the FP64 vector peak -- the reference's arithmetic is "
+                    "double precision; the kernels run the tests in packed single precision with error bands and an exact double-precision fallback.  Staging (half of the kernel) is chains of dependent LDS permutes, loads and classification.  achieved = 23 flop x "
                     "(record, hitpoint) pairs examined%s / kernel time from HIP events on the kernel's stream: ALGORITHMIC operations (the reference's test of a "
                     "pair); the kernels execute fewer%s.  peak 78.6 TFLOP/s counts every operation as an FMA -- the tests run with contraction off "
                     "(bit-exact parity), where the attainable rate is 39.3 T operations/s; traffic = HBM bytes per launch from rocprofv3 --pmc "
@@ -388,7 +388,7 @@ def report(args, world, rule, r, table_name):
                         rule, ("%.0f %%" % (100.0 * pm["valu_active_share"])) if pm and pm.get("valu_active_share") else "most",
                         ("%.0f %%" % (100.0 * pm["lds_active_share"])) if pm and pm.get("lds_active_share") else "less",
                         " + 24 flop x accepted updates" if rule == 0 else "",
-                        " (rule 1 decides the normal and flatness tests of ~80 % of the staged records once per cluster of 64 hitpoints and runs the distance test alone on them, three fused multiply-adds in a form expanded about the cluster's centre)" if rule == 1 else "",
+                        " (rule 1 decides the normal and flatness tests of ~80 % of the staged records once per cluster of 64 hitpoints and runs the distance test alone on them, three packed multiply-adds per two records in a form expanded about the cluster's centre)" if rule == 1 else "",
                         pm.get("run", "the committed run") if pm else "(no committed counters for this workload)"),
         },
     }
