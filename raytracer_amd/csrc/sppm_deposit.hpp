@@ -276,6 +276,21 @@ __global__ void __launch_bounds__(256) k_items_place(const unsigned long long* _
 #define DEP_ATTR __attribute__((amdgpu_waves_per_eu(DEP_WAVES, DEP_WAVES)))
 #define DEP_FLUSH_ROWS 2048  // staged rows after which the double sums move to the 64-bit integers (2048 x 2^41 = 2^52)
 #ifndef DEP_NEAR_MAX
+// (timing experiments, tools/dep_ablation.sh: parts of the kernel compiled out; the default build defines none of these)
+#ifdef DEP_EXP_NOLOAD
+#define DEP_EXP_NOLOAD_V 1
+#else
+#define DEP_EXP_NOLOAD_V 0
+#endif
+#ifdef DEP_EXP_LOAD2
+#define DEP_EXP_L2 0
+#define DEP_EXP_L3 1
+#define DEP_EXP_L4 0
+#else
+#define DEP_EXP_L2 2
+#define DEP_EXP_L3 3
+#define DEP_EXP_L4 4
+#endif
 #define DEP_NEAR_MAX 1e-4
 #ifndef DEP_E32_SCALE
 #define DEP_E32_SCALE 1.0  // (a build with 1e4 here sends every hundredth pair through the exact fallback: how that path was validated)
@@ -525,9 +540,9 @@ __global__ void __launch_bounds__(256) DEP_ATTR k_deposit_tiles(HpArrays hp, Rec
                 }                                                                                                      \
                 p_r = __shfl(g_d, j) + i;                                                                              \
             }                                                                                                          \
-            if (p_has) {                                                                                               \
+            if (p_has && !DEP_EXP_NOLOAD_V) {                                                                          \
                 const double2* rp = (const double2*)(rec.f + (size_t)REC_ROW * p_r);  /* one row: sppm_records.hpp */  \
-                const double2 ra = rp[0], rb = rp[1], rc = rp[2], rd = rp[3], re = rp[4];                              \
+                const double2 ra = rp[0], rb = rp[1], rc = rp[DEP_EXP_L2], rd = rp[DEP_EXP_L3], re = rp[DEP_EXP_L4];   \
                 p0 = ra.x; p1 = ra.y; p2 = rb.x; p3 = rb.y; p4 = rc.x; p5 = rc.y; p6 = rd.x; p7 = rd.y; p8 = re.x;     \
                 if (KEYS) p_key = (unsigned long long)__double_as_longlong(re.y);                                      \
             }                                                                                                          \
@@ -552,7 +567,12 @@ __global__ void __launch_bounds__(256) DEP_ATTR k_deposit_tiles(HpArrays hp, Rec
                 const double nx = fmax(fabs(ux) - bex, 0.0), ny = fmax(fabs(uy) - bey, 0.0), nz = fmax(fabs(uz) - bez, 0.0);
                 const double dmin2 = DEP_H == 1 ? nx * nx + ny * ny + nz * nz : dep_box_dmin2(R, p0, p1, p2);  // (two hitpoints per lane: no centre is made)
                 in = dmin2 <= rmax2;
+#ifdef DEP_EXP_NOCLASS
+                easy = in;
+                if (false) {
+#else
                 if (DEP_H == 1 && in) {
+#endif
                     const double fx_ = fabs(ux) + bex, fy_ = fabs(uy) + bey, fz_ = fabs(uz) + bez;
                     const double dmax2 = fx_ * fx_ + fy_ * fy_ + fz_ * fz_;  // (its margin upwards is in c_rej)
                     const double nd = nbar.x * p3 + nbar.y * p4 + nbar.z * p5;                    // a hitpoint's n.g lies within ndev of it
@@ -568,7 +588,11 @@ __global__ void __launch_bounds__(256) DEP_ATTR k_deposit_tiles(HpArrays hp, Rec
                 }
             }
             const unsigned long long m_e = ballot64(in && easy), m_n = ballot64(in && near), m_f = ballot64(in && !easy && !near);
+#ifdef DEP_EXP_NOWRITE
+            if (false) {
+#else
             if (in) {
+#endif
                 double* row = s_row[wv][easy ? (int)mbcnt64(m_e) : (near ? __popcll(m_e) + (int)mbcnt64(m_n) : DEP_ROWS - 1 - (int)mbcnt64(m_f))];
                 const double f6 = p6, f7 = p7, f8 = p8;  // fixed point already (k_grid_scatter): integer-valued doubles
                 if (F32 && easy) {
@@ -656,6 +680,9 @@ __global__ void __launch_bounds__(256) DEP_ATTR k_deposit_tiles(HpArrays hp, Rec
             }
             const char* eb = (const char*)&s_row[wv][0][0];
             const v2f mx2 = {m2xf, m2xf}, my2 = {m2yf, m2yf}, mz2 = {m2zf, m2zf};
+#ifdef DEP_EXP_SKIP_EASY
+            if (false)
+#endif
             for (int ti = 0; ti < ne_u; ti += 2) {
                 const char* pb = eb + 40 * ti;
                 const v4f A = *(const v4f*)pb, B = *(const v4f*)(pb + 16);
