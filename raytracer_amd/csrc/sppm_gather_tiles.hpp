@@ -366,8 +366,7 @@ __global__ void __launch_bounds__(256) GATHER_WAVES_ATTR k_gather_tiles(HpArrays
                                                       unsigned long long* __restrict__ counters)
 {
     __shared__ unsigned long long s_key[4][64];
-    __shared__ uint32_t s_rec[4][64];
-    __shared__ double s_row[4][64][10];  // the round's candidates in key order: position, geometric normal, key, flux
+    __shared__ __align__(16) double s_row[4][64][10];  // the round's candidates in key order: position, geometric normal, key, flux
     __shared__ __align__(16) float s_fp[4][32][12];  // the same in single precision about the cluster's centre, two candidates per entry: (x0 x1 y0 y1)(z0 z1 gx0 gx1)(gy0 gy1 gz0 gz1)
     const unsigned long long t_entry = STAMPS ? wall_clock64() : 0ull;  // 100 MHz, one clock for the whole device
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -508,14 +507,17 @@ __global__ void __launch_bounds__(256) GATHER_WAVES_ATTR k_gather_tiles(HpArrays
                     const uint32_t r = __shfl(cs, j) + ((uint32_t)i - __shfl(pre, j));
                     bool in = false;
                     unsigned long long key = 0;
+                    double2 ra = {0, 0}, rb = {0, 0}, rc = {0, 0}, rd = {0, 0}, re = {0, 0};
                     if (has) {
                         // (key and position are read together: a slab's cells hold that slab's records, so the key test
                         // nearly always passes, and a second, dependent round trip to memory per group costs more than the bytes)
+                        // The whole row at once, too: what is selected goes straight into the staging rows (unsorted; the rank
+                        // stage permutes them in LDS), so a round has two dependent round trips to memory -- the cell table,
+                        // the rows -- instead of three; the loads are waited for, not counted by their bytes.
                         const double2* rp = (const double2*)(rec.f + (size_t)REC_ROW * r);  // one row: sppm_records.hpp
-                        const double2 ra = rp[0];
-                        const double qz = rp[1].x;
-                        key = (unsigned long long)__double_as_longlong(rp[4].y);
-                        in = key >= klo && key < khi && ra.x >= lx && ra.x <= hx && ra.y >= ly && ra.y <= hy && qz >= lz && qz <= hz;
+                        ra = rp[0]; rb = rp[1]; rc = rp[2]; rd = rp[3]; re = rp[4];
+                        key = (unsigned long long)__double_as_longlong(re.y);
+                        in = key >= klo && key < khi && ra.x >= lx && ra.x <= hx && ra.y >= ly && ra.y <= hy && rb.x >= lz && rb.x <= hz;
                     }
                     c_cand += (unsigned int)__popcll(__ballot(has));
                     const unsigned long long m = __ballot(in);
@@ -524,7 +526,8 @@ __global__ void __launch_bounds__(256) GATHER_WAVES_ATTR k_gather_tiles(HpArrays
                     if (in) {
                         const int slot = sel_n + (int)mbcnt64(m);
                         s_key[wv][slot] = key;
-                        s_rec[wv][slot] = r;
+                        double2* row = (double2*)s_row[wv][slot];  // q, g0, key, flux
+                        row[0] = ra; row[1] = rb; row[2] = rc; row[3] = make_double2(__longlong_as_double((long long)key), rd.x); row[4] = make_double2(rd.y, re.x);
                     }
                     sel_n += cnt;
                 }
@@ -543,13 +546,13 @@ __global__ void __launch_bounds__(256) GATHER_WAVES_ATTR k_gather_tiles(HpArrays
                 d3 q = mk(0, 0, 0), gn = mk(0, 0, 0), pf = mk(0, 0, 0);
                 if (own) {
                     mykey = s_key[wv][lane];
-                    const uint32_t r = s_rec[wv][lane];
-                    const double2* rp = (const double2*)(rec.f + (size_t)REC_ROW * r);
-                    const double2 ra = rp[0], rb = rp[1], rc = rp[2], rd = rp[3], re = rp[4];
-                    q = mk(ra.x, ra.y, rb.x); gn = mk(rb.y, rc.x, rc.y); pf = mk(rd.x, rd.y, re.x);
+                    const double2* row = (const double2*)s_row[wv][lane];
+                    const double2 ra = row[0], rb = row[1], rc = row[2], rd = row[3], re = row[4];
+                    q = mk(ra.x, ra.y, rb.x); gn = mk(rb.y, rc.x, rc.y); pf = mk(rd.y, re.x, re.y);
                 }
                 int rank = 0;
                 for (int jj = 0; jj < sel_n; jj++) rank += (s_key[wv][jj] < mykey) ? 1 : 0;
+                __builtin_amdgcn_wave_barrier();  // (every lane has read its row before any lane writes one at its rank)
                 if (own) {
                     double* row = s_row[wv][rank];  // q, g0, key, flux
                     row[0] = q.x; row[1] = q.y; row[2] = q.z; row[3] = gn.x; row[4] = gn.y; row[5] = gn.z;
