@@ -325,6 +325,8 @@ __global__ void __launch_bounds__(256) DEP_ATTR k_deposit_tiles(HpArrays hp, Rec
     const unsigned int n_waves = gridDim.x * 4u;
 #define DSTAMP() (STAMPS ? (unsigned long long)__builtin_amdgcn_s_memtime() : 0ull)
     unsigned long long st_setup = 0, st_count = 0, st_issue = 0, st_append = 0, st_process = 0, st_flush = 0, st_wait = 0;  // diagnostic build only
+    unsigned long long w_pairs = 0;
+    unsigned int w_acc = 0, w_sel = 0, w_round = 0, w_items = 0;  // (w_acc: per lane, summed over the wavefront at the end; a lane's share of a launch stays far below 2^32)
     for (bool first_item = true;; first_item = false) {
     const unsigned long long ts_item = DSTAMP();
     // persistent wavefronts over the list of items, heaviest first (as k_gather_tiles)
@@ -912,18 +914,23 @@ __global__ void __launch_bounds__(256) DEP_ATTR k_deposit_tiles(HpArrays hp, Rec
     const unsigned long long tf0 = DSTAMP();
     DEP_FLUSH()
 #undef DEP_FLUSH
-    for (int off = 32; off > 0; off >>= 1) c_acc += __shfl_down(c_acc, off);
+    // (the tallies of an item are kept by the wavefront and added to the global counters once, when it runs out of items:
+    // five atomics per item on one cache line, every wavefront waiting for each of its own, were a third of the kernel)
+    w_pairs += c_pairs; w_acc += c_acc; w_sel += c_sel; w_round += c_round; w_items++;
     if (lane == 0) {
-        if (c_pairs) atomicAdd(&counters[3], c_pairs);
-        if (c_acc) atomicAdd(&counters[4], (unsigned long long)c_acc);
-        if (c_sel) atomicAdd(&counters[5], (unsigned long long)c_sel);
-        if (c_round) atomicAdd(&counters[6], (unsigned long long)c_round);
-        atomicAdd(&counters[7], 1ull);
         if (STAMPS) { atomicAdd(&counters[22], d_easy); atomicAdd(&counters[15], d_full); atomicAdd(&counters[8], d_near); atomicAdd(&counters[9], d_near_slow); atomicAdd(&counters[10], d_win); atomicAdd(&counters[11], d_grp); atomicAdd(&counters[12], d_load); atomicAdd(&counters[13], (unsigned long long)Ktot); }
     }
     __builtin_amdgcn_wave_barrier();
     st_flush += DSTAMP() - tf0;
     }  // next item
+    for (int off = 32; off > 0; off >>= 1) w_acc += __shfl_down(w_acc, off);
+    if (lane == 0) {
+        if (w_pairs) atomicAdd(&counters[3], w_pairs);
+        if (w_acc) atomicAdd(&counters[4], (unsigned long long)w_acc);
+        if (w_sel) atomicAdd(&counters[5], (unsigned long long)w_sel);
+        if (w_round) atomicAdd(&counters[6], (unsigned long long)w_round);
+        if (w_items) atomicAdd(&counters[7], (unsigned long long)w_items);
+    }
     if (STAMPS && lane == 0) {
         atomicAdd(&counters[16], st_setup); atomicAdd(&counters[17], st_count); atomicAdd(&counters[18], st_issue);
         atomicAdd(&counters[19], st_append); atomicAdd(&counters[20], st_process); atomicAdd(&counters[21], st_flush); atomicAdd(&counters[23], st_wait);

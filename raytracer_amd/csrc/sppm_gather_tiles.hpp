@@ -386,6 +386,8 @@ __global__ void __launch_bounds__(256) GATHER_WAVES_ATTR k_gather_tiles(HpArrays
     const unsigned int n_items = q[0];
     const unsigned int n_waves = gridDim.x * 4u;
     const bool vetoes = veto_active(tp.veto);
+    unsigned long long w_pairs = 0, w_cyc = 0, m_cyc = 0, m_selk = 0;
+    unsigned int w_cand = 0, w_acc = 0, w_sel = 0, w_round = 0, w_items = 0, m_sel = 0, m_cand = 0, m_round = 0;  // (w_acc: per lane; a wavefront's share of a launch stays far below 2^32)
     for (bool first_item = true;; first_item = false) {
     unsigned int item_i = blockIdx.x * 4u + (unsigned int)wv;
     if (!first_item) {
@@ -665,20 +667,21 @@ __global__ void __launch_bounds__(256) GATHER_WAVES_ATTR k_gather_tiles(HpArrays
         hp.r2[pi] = r2; hp.n[pi] = n;
         hp.flux[pi] = acc.x; hp.flux[P + pi] = acc.y; hp.flux[2 * P + pi] = acc.z;
     }
-    for (int off = 32; off > 0; off >>= 1) c_acc += __shfl_down(c_acc, off);
-    if (lane == 0) {
-        if (c_pairs) atomicAdd(&counters[3], c_pairs);
-        if (c_cand) atomicAdd(&counters[14], (unsigned long long)c_cand);
-        if (c_acc) atomicAdd(&counters[4], (unsigned long long)c_acc);
-        if (c_sel) atomicAdd(&counters[5], (unsigned long long)c_sel);
-        if (c_round) atomicAdd(&counters[6], (unsigned long long)c_round);
-        atomicAdd(&counters[7], 1ull);  // live tiles
-        // work distribution over tiles (read by the SPPM_DEBUG report only)
-        atomicMax(&counters[8], (unsigned long long)c_sel); atomicMax(&counters[9], (unsigned long long)c_cand);
-        atomicMax(&counters[10], (unsigned long long)c_round);
+    // (an item's tallies are kept by the wavefront and reach the global counters once, when it runs out of items: a dozen
+    // atomics per item on one cache line, every wavefront waiting for each of its own, cost the deposit kernel a fifth
+    // of its time -- DESIGN.md section 10, round 3)
+    {
         const unsigned long long cyc = (unsigned long long)(__builtin_amdgcn_s_memtime() - t_start);
-        atomicMax(&counters[11], cyc); atomicAdd(&counters[12], cyc);
-        atomicMax(&counters[13], ((unsigned long long)c_sel << 24) | (unsigned long long)k);
+        w_pairs += c_pairs; w_cand += c_cand; w_acc += c_acc; w_sel += c_sel; w_round += c_round; w_items++;
+        if (STAMPS) {  // (work distribution over tiles: the diagnostic build only)
+            w_cyc += cyc;
+            m_sel = m_sel > c_sel ? m_sel : c_sel; m_cand = m_cand > c_cand ? m_cand : c_cand; m_round = m_round > c_round ? m_round : c_round;
+            m_cyc = m_cyc > cyc ? m_cyc : cyc;
+            const unsigned long long sk = ((unsigned long long)c_sel << 24) | (unsigned long long)k;
+            m_selk = m_selk > sk ? m_selk : sk;
+        }
+    }
+    if (lane == 0) {
         if (STAMPS && tp.item_times) {  // XCC_ID (hardware register 20, bits 3:0): the clock is per XCD
             const unsigned long long xcc = (unsigned long long)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15u);
             tp.item_times[4 * (size_t)item_i] = first_item ? t_entry : w_start; tp.item_times[4 * (size_t)item_i + 1] = (wall_clock64() << 4) | xcc;
@@ -689,5 +692,20 @@ __global__ void __launch_bounds__(256) GATHER_WAVES_ATTR k_gather_tiles(HpArrays
     }
     __builtin_amdgcn_wave_barrier();
     }  // next item
+    for (int off = 32; off > 0; off >>= 1) w_acc += __shfl_down(w_acc, off);
+    if (lane == 0 && w_items) {
+        if (w_pairs) atomicAdd(&counters[3], w_pairs);
+        if (w_cand) atomicAdd(&counters[14], (unsigned long long)w_cand);
+        if (w_acc) atomicAdd(&counters[4], (unsigned long long)w_acc);
+        if (w_sel) atomicAdd(&counters[5], (unsigned long long)w_sel);
+        if (w_round) atomicAdd(&counters[6], (unsigned long long)w_round);
+        atomicAdd(&counters[7], (unsigned long long)w_items);  // live tiles
+        if (STAMPS) {  // work distribution over tiles (read by the SPPM_DEBUG report of the diagnostic build)
+            atomicMax(&counters[8], (unsigned long long)m_sel); atomicMax(&counters[9], (unsigned long long)m_cand);
+            atomicMax(&counters[10], (unsigned long long)m_round);
+            atomicMax(&counters[11], m_cyc); atomicAdd(&counters[12], w_cyc);
+            atomicMax(&counters[13], m_selk);
+        }
+    }
 #undef TSTAMP
 }
