@@ -149,8 +149,8 @@ extern "C" int sppm_create(const sppm_config* cfg, const sppm_sphere* h_spheres,
     c->cell_factor_dep = 0.15;
     { const char* e = getenv("SPPM_DEP_CELL_FACTOR"); if (e && *e && atof(e) > 0.0) c->cell_factor_dep = atof(e); }
     c->dep_chunk = std::max<int64_t>(64, env_i64("SPPM_DEP_CHUNK", 4096));
-    c->dep_light = (double)env_i64("SPPM_DEP_LIGHT", 2100); c->dep_heavy = std::max(c->dep_light + 1.0, (double)env_i64("SPPM_DEP_HEAVY", 2800));
-    c->dep_min = (int)std::min<int64_t>(768, std::max<int64_t>(64, env_i64("SPPM_DEP_MIN", 448) / 64 * 64));
+    c->dep_light = (double)env_i64("SPPM_DEP_LIGHT", 1700); c->dep_heavy = std::max(c->dep_light + 1.0, (double)env_i64("SPPM_DEP_HEAVY", 2400));
+    c->dep_min = (int)std::min<int64_t>(768, std::max<int64_t>(64, env_i64("SPPM_DEP_MIN", 640) / 64 * 64));
     c->rec_first = c->rec_end = 0;
     c->photons_applied = 0;
     c->ns = n_spheres;

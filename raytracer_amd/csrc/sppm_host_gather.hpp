@@ -254,7 +254,10 @@ static int gather_tiles(sppm_ctx* c)
     c->est_valid = 1; c->est_range = range;
     // persistent wavefronts: 4 per SIMD on every CU (fewer if there are few tiles)
     const unsigned int n_items = (unsigned int)c->n_owned * 64u + 64u;  // capacity of the item list (diagnostics only)
-    const int gather_blocks = std::max(1, std::min(nblk(c->n_owned, 4), (int)env_i64("SPPM_GATHER_BLOCKS", 256 * GATHER_WAVES)));
+    // (three and a half of the four wavefront slots of every SIMD: with the tallies kept per wavefront the kernel is short
+    // enough that what runs beside it -- tracer, binning, the next eye pass -- needs the room: 896 against 1024 workgroups,
+    // 165M against 163M photons/s at 20 passes, 320M against 311M at 256)
+    const int gather_blocks = std::max(1, std::min(nblk(c->n_owned, 4), (int)env_i64("SPPM_GATHER_BLOCKS", 224 * GATHER_WAVES)));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (dbg) { HIPCHK(hipMemsetAsync(c->d_counters + 8, 0, 16 * sizeof(unsigned long long), st)); }
     if (c->timing || dbg) { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventRecord(e0, st)); }
