@@ -685,7 +685,24 @@ __global__ void __launch_bounds__(256) DEP_ATTR k_deposit_tiles(HpArrays hp, Rec
 #ifdef DEP_EXP_SKIP_EASY
             if (false)
 #endif
-            for (int ti = 0; ti < ne_u; ti += 2) {
+            int ti = 0;
+            // (four rows per trip while they last: one wait for a trip's LDS reads however many rows it asked for; -3 % kernel time)
+            for (; ti + 2 < ne_u; ti += 4) {
+                const char* pb = eb + 40 * ti;
+                const v4f A = *(const v4f*)pb, B = *(const v4f*)(pb + 16), A2 = *(const v4f*)(pb + 80), B2 = *(const v4f*)(pb + 96);
+                v2d F0 = *(const v2d*)(pb + 32), F1 = *(const v2d*)(pb + 48), F2 = *(const v2d*)(pb + 64);
+                v2d G0 = *(const v2d*)(pb + 112), G1 = *(const v2d*)(pb + 128), G2 = *(const v2d*)(pb + 144);
+                const v2f c = __builtin_elementwise_fma(mz2, B.xy, __builtin_elementwise_fma(my2, A.zw, __builtin_elementwise_fma(mx2, A.xy, B.zw)));
+                const v2f c2 = __builtin_elementwise_fma(mz2, B2.xy, __builtin_elementwise_fma(my2, A2.zw, __builtin_elementwise_fma(mx2, A2.xy, B2.zw)));
+                asm volatile("" : "+v"(F0), "+v"(F1), "+v"(F2), "+v"(G0), "+v"(G1), "+v"(G2));
+                const bool ok0 = c.x < lo32, ok1 = c.y < lo32, ok2 = c2.x < lo32, ok3 = c2.y < lo32;
+                und |= ~(ballot64(ok0) | ballot64(c.x > hi32)) | ~(ballot64(ok1) | ballot64(c.y > hi32)) | ~(ballot64(ok2) | ballot64(c2.x > hi32)) | ~(ballot64(ok3) | ballot64(c2.y > hi32));
+                if (ok0) DEP_TAKE32(F0.x, F0.y, F1.x, ti)
+                if (ok1) DEP_TAKE32(F1.y, F2.x, F2.y, ti + 1)
+                if (ok2) DEP_TAKE32(G0.x, G0.y, G1.x, ti + 2)
+                if (ok3) DEP_TAKE32(G1.y, G2.x, G2.y, ti + 3)
+            }
+            for (; ti < ne_u; ti += 2) {
                 const char* pb = eb + 40 * ti;
                 const v4f A = *(const v4f*)pb, B = *(const v4f*)(pb + 16);
                 v2d F0 = *(const v2d*)(pb + 32), F1 = *(const v2d*)(pb + 48), F2 = *(const v2d*)(pb + 64);
