@@ -380,7 +380,7 @@ def report(args, world, rule, r, table_name):
             "update_bytes_GBps_at_60B": 60.0 * upd0 / max(g_ns, 1), "update_bytes_frac_of_hbm_peak": 60.0 * upd0 / max(g_ns, 1) / 8000.0,
             "note": "rank 0; bound = the vector ALU: the committed SQ counters (profiles/r03_pmc_rule%d.json) show it as the busiest unit of the kernel (VALU busy %s "
                     "of the time every SIMD is occupied, LDS %s, HBM a few percent of 8 TB/s) and the pair loops are bound by the vector instructions they issue (ablation, DESIGN.md 3c), so the roofline is the FP64 vector peak -- the reference's arithmetic is "
-                    "double precision; the kernels run the tests in packed single precision with error bands and an exact double-precision fallback.  Staging (half of the kernel) is chains of dependent LDS permutes, loads and classification.  achieved = 23 flop x "
+                    "double precision; the kernels run the tests in packed single precision with error bands and an exact double-precision fallback.  Staging (a third of the kernel at pass 0, more late in a render) is chains of dependent LDS permutes, loads and classification.  achieved = 23 flop x "
                     "(record, hitpoint) pairs examined%s / kernel time from HIP events on the kernel's stream: ALGORITHMIC operations (the reference's test of a "
                     "pair); the kernels execute fewer%s.  peak 78.6 TFLOP/s counts every operation as an FMA -- the tests run with contraction off "
                     "(bit-exact parity), where the attainable rate is 39.3 T operations/s; traffic = HBM bytes per launch from rocprofv3 --pmc "
