@@ -17,7 +17,7 @@ inside the timed region (scene and state are resident in HBM).
                rank keeps all hitpoints, traces photons [rank M, (rank+1) M) of a pass of N x M, deposits them in 64-bit
                fixed point, ONE all-reduce of 32 bytes per hitpoint per pass; bit-identical for every N.
   0            the reference's live per-photon update (src/sppm2.h:391-421), ordered replay, exact for every N.  N > 1:
-               hitpoints partitioned by ranges of their Morton order, photon-hit records sorted by destination and
+               hitpoints partitioned by ranges of their Hilbert order, photon-hit records sorted by destination and
                exchanged with one all-to-all per batch.
 At N = 1 the other rule is measured in the same run and reported beside the primary line (--one-rule skips it), with
 the relative RMSE between the two images; `k_cap` reports two passes with the reference's K = 10000 cap enforced
@@ -140,7 +140,7 @@ def main_ppm(args, rank, world, barrier):
     1080p.  A step is one batch of --photons photons per GPU applied to the fixed hitpoint list; the timed region
     is a whole render: the eye pass that stores the list, K batches, (N > 1: the all-reduce of the owned hitpoint
     state,) the image.  (sppm_create, outside the region as for the SPPM workload, traces the eye paths once to
-    size the list: reported as create_ms.)  N > 1: the list is shared out by ranges of its Morton order, records
+    size the list: reported as create_ms.)  N > 1: the list is shared out by ranges of its Hilbert order, records
     by all-gather, as for SPPM (raytracer_amd.parallel.ShardedPpm)."""
     import torch
     import torch.distributed as dist

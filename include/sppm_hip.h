@@ -97,7 +97,7 @@ typedef struct sppm_config {
                                 seeds; single GPU, whole passes only, for validation rather than speed. */
     int32_t ownership;       /* which hitpoints this rank gathers for, when tile_stride > 1:
                                 0: the 8x8 pixel tiles tile_first + k*tile_stride (fixed, known without an eye pass);
-                                1: positions [tile_first*P/tile_stride, (tile_first+1)*P/tile_stride) of the Morton
+                                1: positions [tile_first*P/tile_stride, (tile_first+1)*P/tile_stride) of the Hilbert
                                    order of the FIRST eye pass's hitpoints -- a compact region of space per rank, the
                                    same partition on every rank without an exchange (the eye pass is replicated).
                                    Tiles stay as dense as on one GPU and records far from the rank's hitpoints are
@@ -282,7 +282,7 @@ int sppm_download_records(sppm_ctx* ctx, uint64_t* h_key, double* h_f, int64_t* 
 /* d_mask[P] (device, uint8): 1 where this rank owns the pixel's hitpoint (sppm_resolve is meaningful there).
  * No counterpart in the reference: the image of a multi-GPU run is the sum of the ranks' masked images. */
 int sppm_owned_mask(sppm_ctx* ctx, uint8_t* d_mask);
-/* This rank's image indices in gather-tile order (64 consecutive entries form a tile): the Morton
+/* This rank's image indices in gather-tile order (64 consecutive entries form a tile): the Hilbert
  * order of the hitpoint positions made by the last eye pass.  Call with NULL to get the count. */
 int sppm_download_tile_order(sppm_ctx* ctx, int32_t* h_order, int64_t* n);
 /* Accepted (record key, image index) pairs of the gathers since the tap was enabled, sorted by

@@ -19,7 +19,7 @@
 // (fx_fix, the fixed point of the deposits, is applied by k_grid_scatter, sppm_records.hpp: the flux planes this kernel reads hold its bits)
 
 // A wavefront holds DEP_H hitpoints per lane: a tile of the deposit is 64 * DEP_H consecutive hitpoints of the
-// Morton order (lane l holds entries l, 64 + l, ...).  Every staged record is read from LDS once per wavefront
+// Hilbert order (lane l holds entries l, 64 + l, ...).  Every staged record is read from LDS once per wavefront
 // (a broadcast of 72 bytes, which costs the same LDS cycles whether one lane or 64 want it), so with one hitpoint
 // per lane the kernel was bound by the LDS pipe that the four SIMDs of a CU share; two hitpoints per lane halve
 // the LDS reads per (record, hitpoint) pair and leave it bound by the tests' arithmetic.

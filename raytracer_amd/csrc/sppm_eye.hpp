@@ -267,7 +267,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EYE_WA
             if (out.valid[index]) {  // what this thread has just stored, or copied from the view before
                 const double x = out.pos[index], y = out.pos[P + index], z = out.pos[2 * P + index];
                 lo[0] = hi[0] = x; lo[1] = hi[1] = y; lo[2] = hi[2] = z;
-                key = hp_morton_key(x, y, z, ep.bb_prev);
+                key = hp_order_key(x, y, z, ep.bb_prev);
             }
             ep.keys_out[index] = key;
         }

@@ -1,6 +1,6 @@
 // sppm_gather_tiles.hpp -- the tile gather: one wavefront replays, for a tile of 64 spatially
 // neighbouring hitpoints, every photon-hit record near the tile in key (= photon, bounce) order.
-// Tiles are 64 consecutive hitpoints of this rank's pixels sorted along a Morton curve of their
+// Tiles are 64 consecutive hitpoints of this rank's pixels sorted along a Hilbert curve of their
 // positions (re-sorted after every eye pass): screen-space 8x8 tiles are compact on directly seen
 // diffuse surfaces but scattered over the whole scene behind the mirror and glass spheres.
 //
@@ -34,7 +34,7 @@ struct TileParams {
     TileGrid g;
     double gather_r2, alpha;
     int rule;
-    const int32_t* order;  // this rank's image indices, sorted along a Morton curve of the hitpoint positions
+    const int32_t* order;  // this rank's image indices, sorted along a Hilbert curve of the hitpoint positions
     int n_pix, n_owned;    // entries of order[]; virtual tiles = ceil(n_pix / 64)
     double cluster_d;      // lanes farther than this (max norm) from a tile's seed lane are replayed separately
     uint64_t* tap_key; int32_t* tap_pix; unsigned long long* tap_n; int64_t tap_cap;
@@ -86,7 +86,7 @@ __global__ void k_hp_sortkeys(HpArrays hp, const int32_t* __restrict__ pix, int 
     if (i >= n) return;
     const int p = pix[i], P = hp.P;
     if (!hp.valid[p]) { keys[i] = MORTON_INVALID; return; }
-    const hp_key_t code = hp_morton_key(hp.pos[p], hp.pos[P + p], hp.pos[2 * P + p], bb);
+    const hp_key_t code = hp_order_key(hp.pos[p], hp.pos[P + p], hp.pos[2 * P + p], bb);
     keys[i] = code;
 }
 
@@ -229,7 +229,7 @@ __device__ __forceinline__ unsigned int sat_box(const uint32_t* __restrict__ sat
 // percent of all records in a few square units).  A tile there has ~100x the average work, and a tile
 // is replayed by ONE wavefront, so it would set the kernel's duration.  k_tile_est counts the records
 // in each tile's cells; k_tile_emit cuts tiles that exceed a threshold into 2..64 contiguous lane
-// ranges (consecutive lanes are consecutive on the Morton curve, so a range is compact and its region
+// ranges (consecutive lanes are consecutive on the Hilbert curve, so a range is compact and its region
 // smaller); each range becomes a work item replayed by its own wavefront.  Results do not depend on
 // the cut: every hitpoint still sees every record near it, in key order.
 __device__ __forceinline__ uint32_t pack_item(int tile, int lane0, int lanes) { return ((uint32_t)tile << 12) | ((uint32_t)lane0 << 6) | (uint32_t)(lanes - 1); }
@@ -426,7 +426,7 @@ __global__ void __launch_bounds__(256) GATHER_WAVES_ATTR k_gather_tiles(HpArrays
     unsigned long long st_scan = 0, st_rank = 0, st_apply = 0, st_walk = 0, c_walk = 0;   // diagnostic build only (STAMPS)
 #define TSTAMP() (STAMPS ? (unsigned long long)__builtin_amdgcn_s_memtime() : 0ull)
 
-    // A tile is 64 consecutive hitpoints of the Morton order, which is compact except where the curve
+    // A tile is 64 consecutive hitpoints of the Hilbert order, which is compact except where the curve
     // jumps (or where a surface ends).  Lanes far from the seed lane are replayed as a cluster of
     // their own, so that a scattered tile costs the sum of its parts and not their bounding box.
     unsigned long long remaining = __ballot(live);

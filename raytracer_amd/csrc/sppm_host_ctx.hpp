@@ -37,10 +37,10 @@ struct sppm_ctx {
     int64_t rec_first, rec_end;  // photon index range of the records in the buffer
     uint64_t photons_applied; // photons gathered so far (sizes the next batch)
     TileStats* d_stats;
-    // spatial order of this rank's hitpoints (tile gather): own pixel list, Morton keys, sorted order
+    // spatial order of this rank's hitpoints (tile gather): own pixel list, Hilbert keys, sorted order
     int32_t *d_own_pix, *d_order; int n_own_pix;
     uint8_t* d_own_mask;   // [P]
-    int own_pending;       // spatial ownership: the pixel list is cut out of the first eye pass's Morton order
+    int own_pending;       // spatial ownership: the pixel list is cut out of the first eye pass's Hilbert order
     hp_key_t *d_hp_keys, *d_hp_keys_out; unsigned long long* d_hp_bb;
     void* d_sort_tmp; size_t sort_tmp_bytes;
     uint32_t *d_est, *d_items; unsigned long long* d_items_raw; unsigned int* d_item_q; uint8_t* d_n_pieces; unsigned long long* d_est_sum; uint8_t* d_ext_bin; int est_valid;  // d_item_q: [0] items [1] queue head [2..33] per cost class
@@ -77,7 +77,7 @@ struct sppm_ctx {
     unsigned long long *d_rows_n, *h_rows_n; hipEvent_t ev_rows; int rows_pending; int64_t rows_cap;  // sppm_look_ahead_rows
     // Record exchange by destination (sppm_look_ahead_rows_to): with spatial ownership every rank knows every rank's
     // hitpoints (the eye pass is replicated), so it keeps, per view, the occupancy map of EVERY rank and sends a record
-    // only to the ranks whose map holds its cell.  d_all_pix: the first eye pass's whole Morton order (rank r owns
+    // only to the ranks whose map holds its cell.  d_all_pix: the first eye pass's whole Hilbert order (rank r owns
     // positions [r P/N, (r+1) P/N)).
     int all_maps; int32_t* d_all_pix; uint8_t* d_near_all_v[2]; unsigned long long* d_bb_all_v[2]; int view_pass[2]; hipEvent_t ev_view[2];
     unsigned long long *d_rows_n_to, *h_rows_n_to;  // [tile_stride]
@@ -172,7 +172,7 @@ static int dev_alloc(sppm_ctx* c, T** p, size_t n, bool zero = true)
     return 0;
 }
 
-// The sort of the hitpoints' Morton keys runs beside the gather, whose persistent wavefronts leave one wavefront slot of
+// The sort of the hitpoints' Hilbert keys runs beside the gather, whose persistent wavefronts leave one wavefront slot of
 // 128 registers per SIMD.  rocPRIM's tuned Onesweep kernel for these keys and values uses workgroups of 512 threads,
 // two wavefronts per SIMD, which found no room until the gather's tail (one pass of it took 2.4 ms instead of 40 us).
 // The same algorithm (8 bits per pass, match-based ranking) with workgroups of 256 threads fits.

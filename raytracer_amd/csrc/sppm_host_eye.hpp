@@ -210,7 +210,7 @@ static int eye_launch(sppm_ctx* c, int32_t pass, hipStream_t st)
         HIPCHK(hipGetLastError());
     }
     if (c->gather_mode && c->n_own_pix > 0) {
-        // re-form the gather tiles: sort this rank's hitpoints along a Morton curve of their positions, into the next
+        // re-form the gather tiles: sort this rank's hitpoints along a Hilbert curve of their positions, into the next
         // of the three order buffers
         const int slot = c->chain_n % 3;
         c->chain_n++;

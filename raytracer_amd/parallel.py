@@ -5,7 +5,7 @@ What shards and what does not (DESIGN.md "Multi-GPU"):
     photon: a hitpoint's state depends on the time-ordered photons near it, and on nothing else.
     So the hitpoints are partitioned across ranks and every rank replays, for its own hitpoints, the
     photon-hit records of the WHOLE pass in key order.  The result is bit-identical for every world size.
-    Partition (sppm_config.ownership): 1 = contiguous ranges of the Morton order of the first eye pass's
+    Partition (sppm_config.ownership): 1 = contiguous ranges of the Hilbert order of the first eye pass's
     hitpoints, i.e. a compact region of space per rank (default here: tiles stay dense and a rank only
     bins the records near its region); 0 = 8x8 pixel tiles dealt round-robin.
   * Photon tracing is independent per photon (streams keyed by global photon index).  Two ways to
@@ -90,7 +90,7 @@ class ShardedSppm:
             return "1 GPU"
         if self.rule == 1:
             return f"{self.world} ranks: photons sharded by global index, hitpoints replicated, one all-reduce of the fixed-point deposits per pass (in {self.slices} slices)"
-        how = "ranges of the hitpoints' Morton order" if self.ownership == 1 else "8x8 hitpoint tiles dealt round-robin"
+        how = "ranges of the hitpoints' Hilbert order" if self.ownership == 1 else "8x8 hitpoint tiles dealt round-robin"
         return f"{self.world} ranks: hitpoints by {how}, photon records by {self.exchange}"
 
     def step(self, i, resolve=True):
@@ -277,7 +277,7 @@ class ShardedSppm:
 
 class ShardedPpm(ShardedSppm):
     """Classic progressive photon mapping (src/progressive_photonmapping.h) over ranks.  The hitpoint LIST is shared
-    out like SPPM's pixels (every rank traces the whole eye pass, then keeps a range of the list's Morton order);
+    out like SPPM's pixels (every rank traces the whole eye pass, then keeps a range of the list's Hilbert order);
     a step is one batch of photons_per_rank x world photons of the single run of `steps` batches, exchanged like
     SPPM's.  The image sums several hitpoints per pixel, which different ranks may own: finish() first sums the
     ranks' owned state (one all-reduce, exact: one non-zero term per hitpoint) and resolves on every rank."""

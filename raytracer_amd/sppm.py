@@ -52,7 +52,7 @@ def make_config(width, height, *, samples=1, supersamples=1, camera_position=sce
     cfg.check_gather_max = check_gather_max
     cfg.tracer_variant = tracer_variant  # 1 (with sampler 1): create_photon of src/stochastic_ppm.h as shipped
     cfg.algorithm = algorithm  # 0: sppm2.h (stochastic); 1: progressive_photonmapping.h (classic PPM, a list of hitpoints)
-    cfg.ownership = ownership  # with tile_stride > 1 -- 0: 8x8 screen tiles round-robin; 1: ranges of the hitpoints' Morton order
+    cfg.ownership = ownership  # with tile_stride > 1 -- 0: 8x8 screen tiles round-robin; 1: ranges of the hitpoints' Hilbert order
     return cfg
 
 

@@ -217,7 +217,7 @@ def test_classic_ppm_full_size_invariants():
 
 
 def test_classic_ppm_three_ranks_equal_one_context():
-    """The hitpoint list shared out over three 'ranks' (contexts on one GPU) by ranges of its Morton order, records
+    """The hitpoint list shared out over three 'ranks' (contexts on one GPU) by ranges of its Hilbert order, records
     exchanged by hand (pack / append), owned state summed: equal to one context that did everything, bit for bit."""
     import torch
     W, H, M, N = 64, 48, 30000, 3

@@ -117,7 +117,7 @@ def test_config3_per_pass_rule_rank_shares_sum_to_the_pass():
 
 def test_config3_per_photon_rule_one_rank_of_eight():
     """The exact rule over 8 GPUs, one rank's share at full size: rank 3 owns an eighth of the hitpoints (a range of
-    their Morton order), traces its block of every batch and receives the other ranks' records (here: from a helper
+    their Hilbert order), traces its block of every batch and receives the other ranks' records (here: from a helper
     context, through the pack/append rows the exchange carries).  Its hitpoints end up exactly as in one context that
     did the whole 8M-photon pass."""
     import torch

@@ -210,7 +210,7 @@ def test_record_exchange_equals_local_tracing():
 
 
 def test_spatial_ownership_three_ranks_equal_one_context():
-    """ownership = 1 (every rank keeps a range of the Morton order of the first eye pass's hitpoints), three 'ranks'
+    """ownership = 1 (every rank keeps a range of the Hilbert order of the first eye pass's hitpoints), three 'ranks'
     emulated on one GPU with the all-gather flow: the masks partition the pixels, and merged by mask the hitpoint
     state and the image equal a single context that did everything itself, bit for bit.  The binning of these
     ranks drops the records far from their region; nothing near it may be lost."""

@@ -97,7 +97,7 @@ def test_ranks_per_pass_rule_equal_one_gpu(tmp_path, world):
 
 
 def test_two_ranks_classic_ppm_equal_one_gpu(tmp_path):
-    """ShardedPpm: the hitpoint list shared out by ranges of its Morton order, photon records by all-gather, the owned
+    """ShardedPpm: the hitpoint list shared out by ranges of its Hilbert order, photon records by all-gather, the owned
     state summed over the ranks at the end: state and image on every rank equal a single-GPU render, bit for bit."""
     world, W, H, M_rank, steps = 2, 96, 64, 24000, 3
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
